@@ -1,0 +1,144 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4}
+OPT = {"GN": 0, "LM": 1}
+REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
+
+
+class OracleConfig(C.Structure):
+    _fields_ = [("model", C.c_int), ("optimizer", C.c_int), ("max_iterations", C.c_int),
+                ("rotation_eps", C.c_double), ("translation_eps", C.c_double),
+                ("lm_max_iterations", C.c_int), ("lm_init_lambda_factor", C.c_double),
+                ("voxel_resolution", C.c_double), ("num_neighbors", C.c_int), ("knn", C.c_int),
+                ("min_knn", C.c_int), ("max_range", C.c_double), ("plane_threshold", C.c_double),
+                ("max_corr_dist", C.c_double), ("k_correspondences", C.c_int),
+                ("regularization", C.c_int), ("num_threads", C.c_int)]
+
+
+class OracleResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("T64", C.c_double * 16), ("H", C.c_double * 36),
+                ("cost", C.c_double), ("iterations", C.c_int), ("converged", C.c_int),
+                ("num_linearize", C.c_int), ("num_compute_error", C.c_int), ("num_inliers", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libpcm_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(OracleConfig)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_default_config.argtypes = [C.POINTER(OracleConfig)]
+        for f in (L.orc_set_target, L.orc_set_source):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long]
+        L.orc_swap_source_and_target.argtypes = [C.c_void_p]
+        L.orc_linearize.restype = C.c_double
+        L.orc_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_compute_error.restype = C.c_double
+        L.orc_compute_error.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_num_inliers.argtypes = [C.c_void_p]
+        L.orc_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OracleResult)]
+        L.orc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_trace_count.argtypes = [C.c_void_p]
+        L.orc_test_so3_exp.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_test_ldlt6_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_test_esti_plane.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.orc_test_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_test_voxel_key.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 2 and a.shape[1] >= 3
+    return a
+
+
+class Oracle:
+    """CPU oracle registration object (mirrors the pcl::Registration call order)."""
+
+    def __init__(self, model="P2PLANE", optimizer="LM", **kw):
+        L = lib()
+        cfg = OracleConfig()
+        L.orc_default_config(C.byref(cfg))
+        cfg.model = MODEL[model]
+        cfg.optimizer = OPT[optimizer]
+        if "regularization" in kw:
+            kw["regularization"] = REG[kw["regularization"]] if isinstance(kw["regularization"], str) else kw["regularization"]
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise KeyError(k)
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self._h = L.orc_create(C.byref(cfg))
+        self._keep = {}
+        self._trace = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def set_input_target(self, pts):
+        a = _f32(pts); self._keep["t"] = a
+        lib().orc_set_target(self._h, a.ctypes.data, a.shape[0], a.shape[1])
+
+    def set_input_source(self, pts):
+        a = _f32(pts); self._keep["s"] = a
+        lib().orc_set_source(self._h, a.ctypes.data, a.shape[0], a.shape[1])
+
+    def swap_source_and_target(self):
+        lib().orc_swap_source_and_target(self._h)
+
+    def linearize(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        H = np.zeros((6, 6)); b = np.zeros(6)
+        cost = lib().orc_linearize(self._h, T.ctypes.data, H.ctypes.data, b.ctypes.data)
+        return cost, H, b
+
+    def compute_error(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        return lib().orc_compute_error(self._h, T.ctypes.data)
+
+    @property
+    def num_inliers(self):
+        return lib().orc_num_inliers(self._h)
+
+    def enable_trace(self, max_records=256):
+        self._trace = np.zeros((max_records, 43))
+        lib().orc_set_trace(self._h, self._trace.ctypes.data, max_records)
+
+    def trace(self):
+        n = lib().orc_trace_count(self._h)
+        return self._trace[:n].copy()
+
+    def align(self, guess=None):
+        g = np.eye(4, dtype=np.float32) if guess is None else np.ascontiguousarray(guess, dtype=np.float32)
+        res = OracleResult()
+        rc = lib().orc_align(self._h, g.ctypes.data, C.byref(res))
+        if rc != 0:
+            raise RuntimeError("oracle align failed: %d" % rc)
+        return res
+
+
+def result_T(res) -> np.ndarray:
+    return np.array(res.T64[:], dtype=np.float64).reshape(4, 4)

@@ -1,0 +1,63 @@
+/*
+ * oracle/orc_internal.h -- shared state of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ */
+#ifndef ORC_INTERNAL_H
+#define ORC_INTERNAL_H
+
+#include "pcm_oracle.h"
+#include "orc_linalg.h"
+#include <stddef.h>
+
+typedef struct orc_cloud { float *xyz; long n; } orc_cloud;
+
+typedef struct orc_vhash { int *keys; int *val; long cap; long count; } orc_vhash;
+
+typedef struct orc_ivox {
+  orc_vhash h;
+  long nvox;
+  int *vox_start; /* nvox+1 */
+  int *vox_pts;   /* target point indices grouped by voxel, insertion order */
+  int valid;
+} orc_ivox;
+
+typedef struct orc_distpt_buf { void *data; size_t bytes; } orc_distpt_buf;
+
+struct orc_gauss_state;
+
+typedef struct oracle {
+  orc_config cfg;
+  orc_cloud src, tgt;
+  orc_ivox tgt_ivox;
+  float *plane;            /* 4 per source point (last linearize) */
+  unsigned char *selected; /* per source point */
+  long plane_cap;
+  int num_inliers;
+  /* LsqRegistration state */
+  double lm_lambda;
+  double final_hessian[36];
+  double last_cost;
+  int num_linearize, num_compute_error;
+  /* trace */
+  double *trace;
+  int trace_max, trace_n;
+  struct orc_gauss_state *gauss;
+} oracle;
+
+void orc_vhash_init(orc_vhash *h, long expected);
+void orc_vhash_free(orc_vhash *h);
+int orc_vhash_find(const orc_vhash *h, int x, int y, int z);
+int orc_vhash_insert(orc_vhash *h, int x, int y, int z);
+void orc_ivox_key(const oracle *o, const float p[3], int key[3]);
+int orc_ivox_knn(const oracle *o, const float q[3], int *idx_out, float *d2_out, orc_distpt_buf *buf);
+int orc_esti_plane(const float *pts, int n, int K, int min_pts, float threshold, float plane[4]);
+void orc_prepare_model(oracle *o);
+
+/* orc_models_gauss.c: GICP / VGICP / NDT residual models */
+double orc_gauss_linearize(oracle *o, const double T[16], double *H, double *b);
+double orc_gauss_compute_error(oracle *o, const double T[16]);
+void orc_gauss_prepare(oracle *o);
+void orc_gauss_invalidate(oracle *o, int target);
+void orc_gauss_swap(oracle *o);
+void orc_gauss_free(oracle *o);
+
+#endif

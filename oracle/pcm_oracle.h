@@ -1,0 +1,85 @@
+/*
+ * oracle/pcm_oracle.h -- C API of the CPU oracle (ctypes-loaded by tests/ and bench.py).
+ *
+ * TEST INFRASTRUCTURE ONLY: the oracle is the parity checker and the reported
+ * CPU baseline.  The product path (pointcloud-slam_amd/) never includes, links
+ * or loads anything from oracle/.
+ *
+ * PARITY PIN STATUS ("parity unpinned" by the reference's own fixtures): the
+ * reference's hot path cannot be compiled here (needs PCL, FLANN, Boost, a
+ * complete Eigen) and its only known-answer fixture
+ * (fast_gicp/data/relative.txt) refers to two .pcd files that are not in the
+ * tree.  The oracle is therefore a line-by-line restatement self-pinned by
+ * analytic known-answer tests (tests/test_oracle_*.py) and by golden vectors
+ * it generated itself (tests/golden/, script committed).
+ *
+ * All 4x4 transforms crossing this API are ROW-MAJOR.
+ */
+#ifndef PCM_ORACLE_H
+#define PCM_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_MODEL_P2PLANE = 0, ORC_MODEL_GICP = 1, ORC_MODEL_VGICP = 2, ORC_MODEL_NDT_P2D = 3, ORC_MODEL_NDT_D2D = 4 };
+enum { ORC_OPT_GN = 0, ORC_OPT_LM = 1 };
+enum { ORC_REG_NONE = 0, ORC_REG_MIN_EIG = 1, ORC_REG_NORMALIZED_MIN_EIG = 2, ORC_REG_PLANE = 3, ORC_REG_FROBENIUS = 4 };
+
+typedef struct orc_config {
+  int model;
+  int optimizer;              /* lsq_registration_impl.hpp:15 default LM */
+  int max_iterations;         /* :11  64 */
+  double rotation_eps;        /* :12  2e-3 */
+  double translation_eps;     /* :13  5e-4 */
+  int lm_max_iterations;      /* :17  10 */
+  double lm_init_lambda_factor; /* :18 1e-9 */
+  double voxel_resolution;    /* ivox3d.h:54 0.2 | fast_vgicp_impl.hpp:22 1.0 */
+  int num_neighbors;          /* 1, 7, 19 or 27 */
+  int knn;                    /* options.h:14 NUM_MATCH_POINTS 5 */
+  int min_knn;                /* options.h:15 MIN_NUM_MATCH_POINTS 3 */
+  double max_range;           /* ivox3d.h:80 max_range 5.0 */
+  double plane_threshold;     /* options.cc:10 0.1 */
+  double max_corr_dist;       /* fast_gicp_impl.hpp:18 FLT_MAX (GICP) */
+  int k_correspondences;      /* fast_gicp_impl.hpp:16 20 */
+  int regularization;         /* fast_gicp_impl.hpp:20 PLANE */
+  int num_threads;
+} orc_config;
+
+typedef struct orc_result {
+  float T[16];               /* final_transformation_ = x0.cast<float>() (row-major) */
+  double T64[16];            /* x0 before the float cast */
+  double H[36];              /* final_hessian_ */
+  double cost;               /* last linearize() cost */
+  int iterations;            /* nr_iterations_ (index of last outer iteration) */
+  int converged;
+  int num_linearize;         /* passes actually executed (for byte accounting) */
+  int num_compute_error;
+  int num_inliers;           /* correspondences used by the last linearize */
+} orc_result;
+
+void orc_default_config(orc_config *c);
+void *orc_create(const orc_config *c);
+void orc_destroy(void *h);
+int orc_set_target(void *h, const float *xyz, long n, long stride_floats);
+int orc_set_source(void *h, const float *xyz, long n, long stride_floats);
+void orc_swap_source_and_target(void *h);
+double orc_linearize(void *h, const double T[16], double H[36], double b[6]);
+double orc_compute_error(void *h, const double T[16]);
+int orc_num_inliers(void *h);
+int orc_align(void *h, const float guess[16], orc_result *out);
+/* per-iteration trace: each linearize() appends 1+36+6 doubles (cost,H,b) */
+void orc_set_trace(void *h, double *buf, int max_records);
+int orc_trace_count(void *h);
+
+/* building blocks exposed for unit pinning */
+void orc_test_so3_exp(const double omega[3], double R[9]);
+void orc_test_ldlt6_solve(const double A[36], const double b[6], double x[6]);
+int orc_test_esti_plane(const float *pts_xyz, int n, float threshold, float plane[4]);
+int orc_test_knn(void *h, const float q[3], int *idx_out, float *d2_out);
+long orc_test_voxel_key(void *h, const float p[3], int key[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
