@@ -1,0 +1,180 @@
+/*
+ * include/pcm_amd.h -- C ABI of the MI355X-native scan-to-submap registration path.
+ *
+ * This is the drop-in boundary: a plain C interface (pointers + sizes, no
+ * Eigen / PCL / torch types) that the reference's PCL-style operator surface
+ * binds to.  Each entry point cites the reference interface it replaces
+ * (paths relative to /root/reference/src/pointcloud_match/fast_gicp unless
+ * they start with jueying_lio/ or ndt_omp/).  The header-only C++ adapter
+ * include/pcm_amd/registration.hpp re-creates the pcl::Registration subclass
+ * on top of these calls; INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *   - every 4x4 transform is ROW-MAJOR (Eigen::Matrix4f is column-major: the
+ *     adapter transposes);
+ *   - point clouds are arrays of records whose first three floats are x,y,z
+ *     (pcl::PointXYZ stride 16, PointXYZI 32, PointXYZINormal 48 bytes);
+ *   - all functions return 0 on success, a negative pcm_status otherwise, and
+ *     never throw or abort (the reference abort()s on bad enums:
+ *     include/fast_gicp/gicp/fast_vgicp_voxel.hpp:13-15);
+ *   - a context is single-threaded like a pcl::Registration object; different
+ *     contexts may live on different threads / GPUs.
+ */
+#ifndef PCM_AMD_H
+#define PCM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCM_ABI_VERSION 1
+
+typedef enum pcm_status {
+  PCM_OK = 0,
+  PCM_ERR_INVALID_ARGUMENT = -1,
+  PCM_ERR_NO_INPUT = -2,       /* align() before setInputSource/Target */
+  PCM_ERR_HIP = -3,            /* a HIP runtime call failed; see pcm_last_error */
+  PCM_ERR_UNSUPPORTED = -4,
+  PCM_ERR_OUT_OF_RANGE = -5,   /* voxel coordinate outside +-2^20 cells */
+  PCM_ERR_NOT_CONVERGED = -6   /* "lm not converged!!"  impl/lsq_registration_impl.hpp:69-72 (result still written) */
+} pcm_status;
+
+/* residual models */
+typedef enum pcm_model {
+  PCM_MODEL_P2PLANE = 0, /* jueying_lio/src/laser_mapping.cc:592-701  5-NN plane fit, n.p+d */
+  PCM_MODEL_GICP = 1,    /* impl/fast_gicp_impl.hpp:114-237 */
+  PCM_MODEL_VGICP = 2,   /* impl/fast_vgicp_impl.hpp:72-204, src/fast_gicp/cuda/compute_derivatives.cu */
+  PCM_MODEL_NDT_P2D = 3, /* src/fast_gicp/cuda/ndt_compute_derivatives.cu:33-102 */
+  PCM_MODEL_NDT_D2D = 4  /* src/fast_gicp/cuda/ndt_compute_derivatives.cu:104-175 */
+} pcm_model;
+
+/* LSQ_OPTIMIZER_TYPE  include/fast_gicp/gicp/lsq_registration.hpp:13 */
+typedef enum pcm_optimizer { PCM_OPT_GAUSS_NEWTON = 0, PCM_OPT_LEVENBERG_MARQUARDT = 1 } pcm_optimizer;
+
+/* RegularizationMethod  include/fast_gicp/gicp/gicp_settings.hpp:6 */
+typedef enum pcm_regularization {
+  PCM_REG_NONE = 0, PCM_REG_MIN_EIG = 1, PCM_REG_NORMALIZED_MIN_EIG = 2, PCM_REG_PLANE = 3, PCM_REG_FROBENIUS = 4
+} pcm_regularization;
+
+/* where a point buffer lives */
+typedef enum pcm_memory { PCM_MEM_HOST = 0, PCM_MEM_DEVICE = 1 } pcm_memory;
+
+/*
+ * Registration knobs = the reference's plain setters
+ * (setMaximumIterations, setRotationEpsilon, setTransformationEpsilon,
+ *  setInitialLambdaFactor: impl/lsq_registration_impl.hpp:8-38;
+ *  setResolution / setNeighborSearchMethod: impl/fast_vgicp_impl.hpp:28-40;
+ *  ivox_grid_resolution / ivox_nearby_type / esti_plane_threshold:
+ *  jueying_lio/config/livox.yaml:44-46).
+ */
+typedef struct pcm_config {
+  int32_t model;                 /* pcm_model */
+  int32_t optimizer;             /* pcm_optimizer; default LM (lsq_registration_impl.hpp:15) */
+  int32_t max_iterations;        /* 64   (:11) */
+  int32_t lm_max_iterations;     /* 10   (:17) */
+  double rotation_eps;           /* 2e-3 (:12) */
+  double translation_eps;        /* 5e-4 (:13) */
+  double lm_init_lambda_factor;  /* 1e-9 (:18) */
+  float voxel_resolution;        /* iVox / voxel-map cell size [m] */
+  int32_t num_neighbors;         /* 1, 7, 19 or 27 cells searched around the query */
+  int32_t knn;                   /* NUM_MATCH_POINTS 5      jueying_lio/include/options.h:14 */
+  int32_t min_knn;               /* MIN_NUM_MATCH_POINTS 3  jueying_lio/include/options.h:15 */
+  float max_range;               /* GetClosestPoint max_range 5.0  jueying_lio/include/ivox3d/ivox3d.h:80 */
+  float plane_threshold;         /* ESTI_PLANE_THRESHOLD 0.1  jueying_lio/src/options.cc:10 */
+  float max_corr_dist;           /* corr_dist_threshold_ FLT_MAX  impl/fast_gicp_impl.hpp:18 */
+  int32_t k_correspondences;     /* 20  impl/fast_gicp_impl.hpp:16 */
+  int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
+  int32_t sort_source;           /* 1: order the scan along the voxel grid on device (speed only) */
+  int32_t reserved[7];
+} pcm_config;
+
+/* out-parameters of align(): getFinalTransformation / hasConverged /
+ * getFinalHessian / nr_iterations_  (lsq_registration_impl.hpp:40-79) */
+typedef struct pcm_result {
+  float T[16];          /* final_transformation_ = x0.cast<float>()  (:77) */
+  double T64[16];       /* x0 before the float cast */
+  double H[36];         /* final_hessian_ (:119,166) */
+  double cost;          /* cost of the last linearize */
+  int32_t iterations;   /* nr_iterations_ */
+  int32_t converged;    /* converged_ */
+  int32_t num_linearize;      /* linearize passes executed */
+  int32_t num_compute_error;  /* compute_error passes executed (LM) */
+  int32_t num_inliers;        /* correspondences used by the last linearize */
+  int32_t status;             /* pcm_status of this pair */
+} pcm_result;
+
+/* counters for byte accounting / roofline (bench.py) */
+typedef struct pcm_stats {
+  uint64_t linearize_launches;   /* residual-kernel launches since reset */
+  uint64_t point_passes;         /* scan points evaluated (sum over launches) */
+  uint64_t candidates;           /* map points scanned by the kNN search */
+  uint64_t slots_probed;         /* hash slots read */
+  double linearize_ms;           /* HIP-event time of those launches on the context stream */
+  uint64_t target_voxels;        /* occupied voxels of the current target */
+  uint64_t target_slots;         /* hash-table capacity */
+  uint64_t reserved[4];
+} pcm_stats;
+
+typedef struct pcm_ctx pcm_ctx;
+
+/* fills the reference defaults listed above */
+void pcm_default_config(pcm_config *cfg);
+
+/* construct / destroy one registration object bound to a HIP device.
+ * Replaces: FastGICP()/FastVGICPCuda()/NDTCuda() constructors
+ * (impl/fast_gicp_impl.hpp:8-24, impl/fast_vgicp_cuda_impl.hpp:21-38) and the
+ * LaserMapping iVox construction (jueying_lio/src/laser_mapping.cc:16). */
+pcm_ctx *pcm_create(int device, const pcm_config *cfg);
+void pcm_destroy(pcm_ctx *ctx);
+const char *pcm_last_error(const pcm_ctx *ctx);
+int pcm_get_config(const pcm_ctx *ctx, pcm_config *out);
+int pcm_set_config(pcm_ctx *ctx, const pcm_config *cfg);   /* setters; target structures rebuilt lazily if needed */
+int pcm_set_stream(pcm_ctx *ctx, void *hip_stream);        /* run on a caller stream (hipStream_t) */
+
+/* setInputTarget / setInputSource  (impl/fast_gicp_impl.hpp:71-90): `tag` is
+ * the caller's pointer identity; an equal non-zero tag makes the call a no-op,
+ * like the reference's `if (target_ == cloud) return;`.  The library copies
+ * the xyz fields into device memory it owns (voxel hash built here). */
+int pcm_set_target(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory, uint64_t tag);
+int pcm_set_source(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory, uint64_t tag);
+int pcm_swap_source_and_target(pcm_ctx *ctx);              /* impl/fast_gicp_impl.hpp:50-58 */
+int pcm_clear_source(pcm_ctx *ctx);                        /* :60-64 */
+int pcm_clear_target(pcm_ctx *ctx);                        /* :66-69 */
+
+/* pcl::Registration::align(out, guess) -> computeTransformation
+ * (impl/lsq_registration_impl.hpp:52-79).  Transforming the output cloud is
+ * left to the adapter (pcl::transformPointCloud, :78). */
+int pcm_align(pcm_ctx *ctx, const float guess[16], pcm_result *out);
+
+/* LsqRegistration::evaluateCost -> linearize (lsq_registration_impl.hpp:46-49)
+ * and compute_error (impl/fast_gicp_impl.hpp:213-237). H,b may be NULL. */
+int pcm_linearize(pcm_ctx *ctx, const double T[16], double H[36], double b[6], double *cost, int32_t *num_inliers);
+int pcm_compute_error(pcm_ctx *ctx, const double T[16], double *cost);
+
+/* parity hook: the plane (nx,ny,nz,d) fitted to every scan point by the last
+ * pcm_linearize (plane_coef_ of jueying_lio/src/laser_mapping.cc:621-622), in the
+ * scan's device order; nx = NaN marks a point that was not selected.  `out`
+ * holds 4*n floats. */
+int pcm_get_planes(pcm_ctx *ctx, float *out, size_t n);
+
+/* Batch of independent registration objects on one device (BASELINE config 3:
+ * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel
+ * launches, no host round trip per iteration.  `guesses` = n x 16 floats.
+ * `host_out` (n results) and/or `device_out` (device pointer to n packed
+ * pcm_result records, e.g. the buffer handed to an RCCL all_gather) may be NULL. */
+int pcm_align_batch(pcm_ctx *const *ctxs, int n, const float *guesses, pcm_result *host_out, void *device_out);
+
+/* profiling on: residual launches are bracketed by HIP events and the kNN
+ * candidate / probe counters are collected (adds a few atomics per workgroup) */
+int pcm_set_profiling(pcm_ctx *ctx, int on);
+int pcm_get_stats(pcm_ctx *ctx, pcm_stats *out);
+int pcm_reset_stats(pcm_ctx *ctx);
+int pcm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCM_AMD_H */

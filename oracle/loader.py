@@ -55,6 +55,7 @@ def lib():
         L.orc_compute_error.restype = C.c_double
         L.orc_compute_error.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_num_inliers.argtypes = [C.c_void_p]
+        L.orc_get_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
         L.orc_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OracleResult)]
         L.orc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace_count.argtypes = [C.c_void_p]
@@ -122,6 +123,12 @@ class Oracle:
     @property
     def num_inliers(self):
         return lib().orc_num_inliers(self._h)
+
+    def get_planes(self, n):
+        pl = np.zeros((n, 4), np.float32); sel = np.zeros(n, np.uint8)
+        if lib().orc_get_planes(self._h, pl.ctypes.data, sel.ctypes.data, n) != 0:
+            raise RuntimeError("orc_get_planes")
+        return pl, sel.astype(bool)
 
     def enable_trace(self, max_records=256):
         self._trace = np.zeros((max_records, 43))

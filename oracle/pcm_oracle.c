@@ -594,6 +594,14 @@ double orc_compute_error(void *h, const double T[16]) {
   return model_compute_error(o, T);
 }
 
+int orc_get_planes(void *h, float *planes, unsigned char *selected, long n) {
+  oracle *o = (oracle *)h;
+  if (n != o->src.n || !o->plane) return -1;
+  memcpy(planes, o->plane, sizeof(float) * 4 * (size_t)n);
+  memcpy(selected, o->selected, (size_t)n);
+  return 0;
+}
+
 int orc_num_inliers(void *h) { return ((oracle *)h)->num_inliers; }
 
 void orc_set_trace(void *h, double *buf, int max_records) {

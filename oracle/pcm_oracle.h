@@ -67,6 +67,8 @@ void orc_swap_source_and_target(void *h);
 double orc_linearize(void *h, const double T[16], double H[36], double b[6]);
 double orc_compute_error(void *h, const double T[16]);
 int orc_num_inliers(void *h);
+/* planes (4 floats) + selected flag of every source point from the last linearize */
+int orc_get_planes(void *h, float *planes, unsigned char *selected, long n);
 int orc_align(void *h, const float guess[16], orc_result *out);
 /* per-iteration trace: each linearize() appends 1+36+6 doubles (cost,H,b) */
 void orc_set_trace(void *h, double *buf, int max_records);

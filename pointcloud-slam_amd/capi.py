@@ -1,0 +1,115 @@
+"""ctypes binding of libpcm_amd.so (the C ABI declared in include/pcm_amd.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/pcm_amd.h declares (tests check the .so exports each one)
+SYMBOLS = [
+    "pcm_abi_version", "pcm_default_config", "pcm_create", "pcm_destroy", "pcm_last_error",
+    "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
+    "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
+    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_align_batch", "pcm_set_profiling",
+    "pcm_get_stats", "pcm_reset_stats",
+]
+
+PCM_OK = 0
+PCM_ERR_NOT_CONVERGED = -6
+MEM_HOST, MEM_DEVICE = 0, 1
+MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4}
+OPTIMIZER = {"GN": 0, "LM": 1}
+REGULARIZATION = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
+
+
+class PcmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pcm error %d: %s" % (code, msg))
+        self.code = code
+
+
+class PcmConfig(C.Structure):
+    _fields_ = [("model", C.c_int32), ("optimizer", C.c_int32), ("max_iterations", C.c_int32),
+                ("lm_max_iterations", C.c_int32), ("rotation_eps", C.c_double),
+                ("translation_eps", C.c_double), ("lm_init_lambda_factor", C.c_double),
+                ("voxel_resolution", C.c_float), ("num_neighbors", C.c_int32), ("knn", C.c_int32),
+                ("min_knn", C.c_int32), ("max_range", C.c_float), ("plane_threshold", C.c_float),
+                ("max_corr_dist", C.c_float), ("k_correspondences", C.c_int32),
+                ("regularization", C.c_int32), ("sort_source", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class PcmResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("T64", C.c_double * 16), ("H", C.c_double * 36),
+                ("cost", C.c_double), ("iterations", C.c_int32), ("converged", C.c_int32),
+                ("num_linearize", C.c_int32), ("num_compute_error", C.c_int32),
+                ("num_inliers", C.c_int32), ("status", C.c_int32)]
+
+
+class PcmStats(C.Structure):
+    _fields_ = [("linearize_launches", C.c_uint64), ("point_passes", C.c_uint64),
+                ("candidates", C.c_uint64), ("slots_probed", C.c_uint64), ("linearize_ms", C.c_double),
+                ("target_voxels", C.c_uint64), ("target_slots", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libpcm_amd.so")
+
+
+def build_library(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    so = library_path()
+    src_dir = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include", "pcm_amd.h")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h"))] + [inc]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", src_dir, "-s", "-j4"])
+    return so
+
+
+def load_library():
+    """Load libpcm_amd.so.  Raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7
+    # (same SONAME as /opt/rocm's).  If libpcm_amd.so pulled in the system copy
+    # first, a later `import torch` would load a second runtime that finds no GPU;
+    # importing torch first lets the dynamic loader reuse torch's copy for us.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    so = library_path()
+    if not os.path.exists(so):
+        raise PcmError(-3, "libpcm_amd.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(so)
+    vp, i32, u64, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
+    L.pcm_abi_version.restype = i32
+    L.pcm_default_config.argtypes = [C.POINTER(PcmConfig)]
+    L.pcm_default_config.restype = None
+    L.pcm_create.argtypes = [i32, C.POINTER(PcmConfig)]
+    L.pcm_create.restype = vp
+    L.pcm_destroy.argtypes = [vp]
+    L.pcm_destroy.restype = None
+    L.pcm_last_error.argtypes = [vp]
+    L.pcm_last_error.restype = C.c_char_p
+    L.pcm_get_config.argtypes = [vp, C.POINTER(PcmConfig)]
+    L.pcm_set_config.argtypes = [vp, C.POINTER(PcmConfig)]
+    L.pcm_set_stream.argtypes = [vp, vp]
+    for f in (L.pcm_set_target, L.pcm_set_source):
+        f.argtypes = [vp, vp, sz, sz, i32, u64]
+    for f in (L.pcm_swap_source_and_target, L.pcm_clear_source, L.pcm_clear_target, L.pcm_reset_stats):
+        f.argtypes = [vp]
+    L.pcm_align.argtypes = [vp, vp, C.POINTER(PcmResult)]
+    L.pcm_linearize.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.pcm_compute_error.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    L.pcm_get_planes.argtypes = [vp, vp, sz]
+    L.pcm_align_batch.argtypes = [C.POINTER(vp), i32, vp, vp, vp]
+    L.pcm_set_profiling.argtypes = [vp, i32]
+    L.pcm_get_stats.argtypes = [vp, C.POINTER(PcmStats)]
+    _LIB = L
+    return L

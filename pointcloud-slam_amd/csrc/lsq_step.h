@@ -1,0 +1,227 @@
+// lsq_step.h -- Gauss-Newton / Levenberg-Marquardt outer-loop arithmetic, usable
+// from host and device code (double precision throughout).
+//
+// Follows fast_gicp's LsqRegistration
+// (/root/reference/src/pointcloud_match/fast_gicp/include/fast_gicp/gicp/impl/lsq_registration_impl.hpp:52-172)
+// re-expressed as a per-pair state machine so a whole batch of registrations
+// advances with one residual kernel + one step kernel per round and no host
+// round trip: LINEARIZE round -> (LM only) TRIAL rounds -> next LINEARIZE.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace pcm {
+
+#define PCM_HD __host__ __device__ inline
+
+enum PairMode : int32_t { MODE_LINEARIZE = 0, MODE_TRIAL = 1, MODE_DONE = 2 };
+
+// Per-pair optimiser state, resident in device memory for the whole align().
+struct PairState {
+  double x0[16];        // current pose (row-major Isometry3d)
+  double xi[16];        // LM trial pose
+  double delta[16];     // last update
+  double H[36];         // normal matrix of the last linearize
+  double b[6];
+  double final_hessian[36];
+  double y0;            // cost at x0
+  double lambda;        // lm_lambda_ (<0: uninitialised)
+  double nu;
+  double d[6];
+  int32_t mode;         // PairMode
+  int32_t iter;         // outer iteration index i (nr_iterations_)
+  int32_t lm_inner;     // inner LM try index
+  int32_t converged;
+  int32_t status;
+  int32_t num_linearize;
+  int32_t num_compute_error;
+  int32_t num_inliers;
+  double last_cost;
+};
+
+struct LsqParams {
+  int32_t optimizer;  // 0 GN, 1 LM
+  int32_t max_iterations;
+  int32_t lm_max_iterations;
+  double rotation_eps;
+  double translation_eps;
+  double lm_init_lambda_factor;
+};
+
+PCM_HD void iso_mul(const double* A, const double* B, double* C) {
+  double R[16];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[i * 4 + j] = A[i * 4 + 0] * B[j] + A[i * 4 + 1] * B[4 + j] + A[i * 4 + 2] * B[8 + j];
+    R[i * 4 + 3] = A[i * 4 + 0] * B[3] + A[i * 4 + 1] * B[7] + A[i * 4 + 2] * B[11] + A[i * 4 + 3];
+  }
+  R[12] = R[13] = R[14] = 0.0;
+  R[15] = 1.0;
+  for (int i = 0; i < 16; i++) C[i] = R[i];
+}
+
+// so3_exp (so3.hpp:58-77) followed by Quaternion::toRotationMatrix, and the
+// translation part: delta = [exp(d[0:3]) | d[3:6]]  (lsq_registration_impl.hpp:114-116)
+PCM_HD void delta_from_d(const double* d, double* delta) {
+  const double theta_sq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double theta_quad = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * theta_quad;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * theta_quad;
+  } else {
+    const double theta = sqrt(theta_sq);
+    const double half = 0.5 * theta;
+    imag = sin(half) / theta;
+    real = cos(half);
+  }
+  const double w = real, x = imag * d[0], y = imag * d[1], z = imag * d[2];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  delta[0] = 1 - (tyy + tzz); delta[1] = txy - twz;       delta[2] = txz + twy;        delta[3] = d[3];
+  delta[4] = txy + twz;       delta[5] = 1 - (txx + tzz); delta[6] = tyz - twx;        delta[7] = d[4];
+  delta[8] = txz - twy;       delta[9] = tyz + twx;       delta[10] = 1 - (txx + tyy); delta[11] = d[5];
+  delta[12] = 0; delta[13] = 0; delta[14] = 0; delta[15] = 1;
+}
+
+// LDL^T with diagonal pivoting (what Eigen::LDLT does, lsq_registration_impl.hpp:111,136)
+PCM_HD void ldlt6_solve(const double* Ain, const double* rhs, double* x) {
+  double A[36];
+  int perm[6];
+  for (int i = 0; i < 36; i++) A[i] = Ain[i];
+  for (int i = 0; i < 6; i++) perm[i] = i;
+  for (int k = 0; k < 6; k++) {
+    int p = k;
+    double best = fabs(A[k * 6 + k]);
+    for (int i = k + 1; i < 6; i++) {
+      const double v = fabs(A[i * 6 + i]);
+      if (v > best) { best = v; p = i; }
+    }
+    if (p != k) {
+      for (int j = 0; j < 6; j++) { const double t = A[k * 6 + j]; A[k * 6 + j] = A[p * 6 + j]; A[p * 6 + j] = t; }
+      for (int i = 0; i < 6; i++) { const double t = A[i * 6 + k]; A[i * 6 + k] = A[i * 6 + p]; A[i * 6 + p] = t; }
+      const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+    }
+    const double dk = A[k * 6 + k];
+    if (dk == 0.0) continue;
+    for (int i = k + 1; i < 6; i++) A[i * 6 + k] /= dk;
+    for (int i = k + 1; i < 6; i++) {
+      for (int j = k + 1; j <= i; j++) {
+        A[i * 6 + j] -= A[i * 6 + k] * dk * A[j * 6 + k];
+        A[j * 6 + i] = A[i * 6 + j];
+      }
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) y[i] = rhs[perm[i]];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < i; j++) y[i] -= A[i * 6 + j] * y[j];
+  for (int i = 0; i < 6; i++) y[i] = (fabs(A[i * 6 + i]) > 2.2250738585072014e-308) ? y[i] / A[i * 6 + i] : 0.0;
+  for (int i = 5; i >= 0; i--) for (int j = i + 1; j < 6; j++) y[i] -= A[j * 6 + i] * y[j];
+  for (int i = 0; i < 6; i++) x[perm[i]] = y[i];
+}
+
+// is_converged  (lsq_registration_impl.hpp:81-91)
+PCM_HD bool is_converged(const LsqParams& p, const double* delta) {
+  double rmax = 0.0, tmax = 0.0;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      const double r = fabs(delta[i * 4 + j] - (i == j ? 1.0 : 0.0)) * (1.0 / p.rotation_eps);
+      rmax = r > rmax ? r : rmax;
+    }
+    const double t = fabs(delta[i * 4 + 3]) * (1.0 / p.translation_eps);
+    tmax = t > tmax ? t : tmax;
+  }
+  return (rmax > tmax ? rmax : tmax) < 1.0;
+}
+
+PCM_HD void solve_damped(PairState& s, double lambda) {
+  double A[36], nb[6];
+  for (int i = 0; i < 36; i++) A[i] = s.H[i];
+  for (int k = 0; k < 6; k++) { A[k * 6 + k] += lambda; nb[k] = -s.b[k]; }
+  ldlt6_solve(A, nb, s.d);
+  delta_from_d(s.d, s.delta);
+}
+
+// end of one outer iteration: `converged_ = is_converged(delta)` and the loop
+// condition of computeTransformation (lsq_registration_impl.hpp:63-75)
+PCM_HD void finish_outer(PairState& s, const LsqParams& p, bool step_ok) {
+  if (!step_ok) {  // "lm not converged!!" -> break (:69-72)
+    s.status = -6;
+    s.mode = MODE_DONE;
+    return;
+  }
+  s.converged = is_converged(p, s.delta) ? 1 : 0;
+  if (s.converged || s.iter + 1 >= p.max_iterations) {
+    s.mode = MODE_DONE;
+  } else {
+    s.iter += 1;
+    s.mode = MODE_LINEARIZE;
+  }
+}
+
+// Called after a LINEARIZE round produced (H, b, cost) at x0.
+PCM_HD void after_linearize(PairState& s, const LsqParams& p, const double* H, const double* b, double cost, int inliers) {
+  for (int i = 0; i < 36; i++) s.H[i] = H[i];
+  for (int i = 0; i < 6; i++) s.b[i] = b[i];
+  s.y0 = cost;
+  s.last_cost = cost;
+  s.num_linearize += 1;
+  s.num_inliers = inliers;
+  if (p.optimizer == 0) {  // step_gn (:105-122)
+    solve_damped(s, 0.0);
+    iso_mul(s.delta, s.x0, s.x0);
+    for (int i = 0; i < 36; i++) s.final_hessian[i] = s.H[i];
+    finish_outer(s, p, true);
+    return;
+  }
+  // step_lm head (:124-143)
+  if (s.lambda < 0.0) {
+    double mx = 0.0;
+    for (int i = 0; i < 6; i++) { const double v = fabs(s.H[i * 6 + i]); mx = v > mx ? v : mx; }
+    s.lambda = p.lm_init_lambda_factor * mx;
+  }
+  s.nu = 2.0;
+  s.lm_inner = 0;
+  if (p.lm_max_iterations <= 0) { finish_outer(s, p, false); return; }
+  solve_damped(s, s.lambda);
+  iso_mul(s.delta, s.x0, s.xi);
+  s.mode = MODE_TRIAL;
+}
+
+// Called after a TRIAL round produced cost yi at xi  (:144-171)
+PCM_HD void after_trial(PairState& s, const LsqParams& p, double yi) {
+  s.num_compute_error += 1;
+  double den = 0.0;
+  for (int k = 0; k < 6; k++) den += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
+  const double rho = (s.y0 - yi) / den;
+  if (rho < 0) {
+    if (is_converged(p, s.delta)) { finish_outer(s, p, true); return; }
+    s.lambda = s.nu * s.lambda;
+    s.nu = 2 * s.nu;
+    s.lm_inner += 1;
+    if (s.lm_inner >= p.lm_max_iterations) { finish_outer(s, p, false); return; }
+    solve_damped(s, s.lambda);
+    iso_mul(s.delta, s.x0, s.xi);
+    s.mode = MODE_TRIAL;
+    return;
+  }
+  for (int i = 0; i < 16; i++) s.x0[i] = s.xi[i];
+  const double c = 2 * rho - 1;
+  const double f = 1 - c * c * c;
+  s.lambda = s.lambda * (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
+  for (int i = 0; i < 36; i++) s.final_hessian[i] = s.H[i];
+  finish_outer(s, p, true);
+}
+
+PCM_HD void init_state(PairState& s, const float* guess) {
+  for (int i = 0; i < 16; i++) { s.x0[i] = (double)guess[i]; s.xi[i] = s.x0[i]; s.delta[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  for (int i = 0; i < 36; i++) { s.H[i] = 0.0; s.final_hessian[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  for (int i = 0; i < 6; i++) { s.b[i] = 0.0; s.d[i] = 0.0; }
+  s.y0 = 0.0; s.lambda = -1.0; s.nu = 2.0;
+  s.mode = MODE_LINEARIZE; s.iter = 0; s.lm_inner = 0; s.converged = 0; s.status = 0;
+  s.num_linearize = 0; s.num_compute_error = 0; s.num_inliers = 0; s.last_cost = 0.0;
+}
+
+}  // namespace pcm

@@ -1,0 +1,531 @@
+// pcm_api.hip -- the C ABI of include/pcm_amd.h: registration objects, the batched
+// device-resident GN/LM loop and the parity hooks (linearize / compute_error).
+//
+// Host-side counterpart of the reference's wrappers
+//   FastVGICPCuda / NDTCuda host classes   /root/reference/src/pointcloud_match/fast_gicp/include/fast_gicp/gicp/impl/fast_vgicp_cuda_impl.hpp:21-180
+//   LsqRegistration::computeTransformation  .../impl/lsq_registration_impl.hpp:52-79
+// The reference crosses host<->device >= 4 times per Gauss-Newton iteration
+// (SURVEY.md §2.3); here the loop state lives on the device and the host only
+// polls a per-round "pairs still active" counter one round behind the GPU.
+#include "pcm_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+using namespace pcm;
+
+namespace {
+
+#define HIPCK(ctx, x)                                                                \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) {                                                          \
+      (ctx)->err = std::string(#x) + ": " + hipGetErrorString(e_);                   \
+      return PCM_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+
+// grow-only device workspace shared by the batch launches of one device
+struct Workspace {
+  int device = -1;
+  PairDesc* d_descs = nullptr;
+  PairState* d_states = nullptr;
+  float* d_guesses = nullptr;
+  pcm_result* d_results = nullptr;
+  double* d_partials = nullptr;
+  double* d_sums = nullptr;
+  int* d_active = nullptr;
+  int* h_active = nullptr;  // pinned
+  unsigned long long* d_stats = nullptr;
+  int cap_pairs = 0;
+  size_t cap_partials = 0;
+  int cap_rounds = 0;
+  std::vector<hipEvent_t> ev_round;
+  std::vector<hipEvent_t> ev_prof;
+};
+
+std::mutex g_ws_mutex;
+Workspace g_ws[16];
+
+int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, int rounds) {
+  if (c->device < 0 || c->device >= 16) { c->err = "device index out of range"; return PCM_ERR_INVALID_ARGUMENT; }
+  Workspace& w = g_ws[c->device];
+  w.device = c->device;
+  if (npairs > w.cap_pairs) {
+    if (w.d_descs) { hipFree(w.d_descs); hipFree(w.d_states); hipFree(w.d_guesses); hipFree(w.d_results); hipFree(w.d_sums); }
+    const int cap = std::max(npairs, 64);
+    HIPCK(c, hipMalloc(&w.d_descs, sizeof(PairDesc) * cap));
+    HIPCK(c, hipMalloc(&w.d_states, sizeof(PairState) * cap));
+    HIPCK(c, hipMalloc(&w.d_guesses, sizeof(float) * 16 * cap));
+    HIPCK(c, hipMalloc(&w.d_results, sizeof(pcm_result) * cap));
+    HIPCK(c, hipMalloc(&w.d_sums, sizeof(double) * kPartialStride * cap));
+    w.cap_pairs = cap;
+  }
+  if (partial_doubles > w.cap_partials) {
+    if (w.d_partials) hipFree(w.d_partials);
+    HIPCK(c, hipMalloc(&w.d_partials, sizeof(double) * partial_doubles));
+    w.cap_partials = partial_doubles;
+  }
+  if (rounds > w.cap_rounds) {
+    if (w.d_active) { hipFree(w.d_active); hipHostFree(w.h_active); }
+    HIPCK(c, hipMalloc(&w.d_active, sizeof(int) * rounds));
+    HIPCK(c, hipHostMalloc(&w.h_active, sizeof(int) * rounds));
+    w.cap_rounds = rounds;
+  }
+  if (!w.d_stats) HIPCK(c, hipMalloc(&w.d_stats, sizeof(unsigned long long) * 4));
+  while ((int)w.ev_round.size() < 2) {
+    hipEvent_t e;
+    HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    w.ev_round.push_back(e);
+  }
+  *out = &w;
+  return PCM_OK;
+}
+
+int coord_mode_for(int model) { return model == PCM_MODEL_P2PLANE ? COORD_ROUND : COORD_FLOOR_HALF; }
+
+int validate_config(pcm_ctx* c, const pcm_config& g) {
+  if (g.model != PCM_MODEL_P2PLANE) { c->err = "model not built in this library revision"; return PCM_ERR_UNSUPPORTED; }
+  if (g.optimizer != PCM_OPT_GAUSS_NEWTON && g.optimizer != PCM_OPT_LEVENBERG_MARQUARDT) { c->err = "bad optimizer"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (!(g.voxel_resolution > 0.f)) { c->err = "voxel_resolution must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (g.num_neighbors != 1 && g.num_neighbors != 7 && g.num_neighbors != 19 && g.num_neighbors != 27) {
+    c->err = "num_neighbors must be 1, 7, 19 or 27"; return PCM_ERR_INVALID_ARGUMENT;
+  }
+  if (g.knn != 5 || g.min_knn != 3) { c->err = "knn/min_knn are the reference constants 5/3 (options.h:14-15)"; return PCM_ERR_UNSUPPORTED; }
+  if (!(g.rotation_eps > 0) || !(g.translation_eps > 0)) { c->err = "epsilons must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
+  return PCM_OK;
+}
+
+int set_cloud(pcm_ctx* c, Cloud* cl, const void* points, size_t n, size_t stride, int memory, uint64_t tag) {
+  if (!points && n) { c->err = "null point buffer"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (stride < 3 * sizeof(float) || (stride % sizeof(float)) != 0) { c->err = "stride must be a multiple of 4 and >= 12 bytes"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (n > 0x7fffffffull) { c->err = "cloud too large"; return PCM_ERR_INVALID_ARGUMENT; }
+  HIPCK(c, hipSetDevice(c->device));
+  if (n > cl->cap) {
+    if (cl->d_pts) hipFree(cl->d_pts);
+    cl->d_pts = nullptr; cl->cap = 0;
+    HIPCK(c, hipMalloc(&cl->d_pts, sizeof(float4) * n));
+    cl->cap = n;
+  }
+  cl->n = n;
+  cl->tag = tag;
+  int rc = load_points_to_device(c->stream, points, n, stride, memory, cl->d_pts, &c->err);
+  if (rc != PCM_OK) return rc;
+  HIPCK(c, hipStreamSynchronize(c->stream));  // the caller may free/reuse its buffer on return
+  return PCM_OK;
+}
+
+// lazy (re)build of everything the residual kernel needs
+int prepare(pcm_ctx* c) {
+  if (c->src.n == 0 || c->tgt.n == 0) { c->err = "align before setInputSource/setInputTarget"; return PCM_ERR_NO_INPUT; }
+  HIPCK(c, hipSetDevice(c->device));
+  const int mode = coord_mode_for(c->cfg.model);
+  if (!c->map.valid || c->map.res != c->cfg.voxel_resolution || c->map.coord_mode != mode) {
+    int rc = build_target_map(c->stream, c->tgt.d_pts, (uint32_t)c->tgt.n, c->cfg.voxel_resolution, mode, &c->map, &c->err);
+    if (rc != PCM_OK) return rc;
+    c->stats.target_voxels = c->map.num_voxels;
+    c->stats.target_slots = c->map.cap;
+  }
+  if (c->cfg.sort_source && !c->src_sorted) {
+    int rc = sort_source_along_grid(c->stream, c->src.d_pts, (uint32_t)c->src.n, c->cfg.voxel_resolution, &c->err);
+    if (rc != PCM_OK) return rc;
+    c->src_sorted = true;
+  }
+  if (c->planes_cap < c->src.n) {
+    if (c->planes) hipFree(c->planes);
+    c->planes = nullptr; c->planes_cap = 0;
+    HIPCK(c, hipMalloc(&c->planes, sizeof(float4) * c->src.n));
+    c->planes_cap = c->src.n;
+  }
+  return PCM_OK;
+}
+
+struct Geom {
+  int blocks_per_pair;
+  int points_per_block;
+};
+
+Geom pick_geom(size_t max_n, int npairs) {
+  // aim at >= ~4096 workgroups in flight over the 256 CUs; each lane then
+  // amortises the 29-value wave reduction over several points
+  size_t total = max_n * (size_t)npairs;
+  size_t ppb = (total / 4096 + 255) / 256 * 256;
+  ppb = std::min<size_t>(std::max<size_t>(ppb, 256), 2048);
+  Geom g;
+  g.points_per_block = (int)ppb;
+  g.blocks_per_pair = (int)((max_n + ppb - 1) / ppb);
+  return g;
+}
+
+void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
+  d->tgt.pts = c->map.pts;
+  d->tgt.slots = c->map.slots;
+  d->tgt.mask = c->map.cap - 1;
+  d->tgt.num_points = c->map.num_points;
+  d->tgt.inv_res = c->map.inv_res;
+  d->tgt.res = c->map.res;
+  d->src.pts = c->src.d_pts;
+  d->src.num_points = (uint32_t)c->src.n;
+  d->planes = c->planes;
+  d->partials = partials;
+}
+
+KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
+  KernelParams kp{};
+  kp.num_neighbors = g.num_neighbors;
+  kp.knn = g.knn;
+  kp.min_knn = g.min_knn;
+  kp.max_range_sq = (double)g.max_range * (double)g.max_range;
+  kp.plane_threshold = g.plane_threshold;
+  kp.blocks_per_pair = geom.blocks_per_pair;
+  kp.points_per_block = geom.points_per_block;
+  return kp;
+}
+
+LsqParams lsq_params(const pcm_config& g) {
+  LsqParams lp{};
+  lp.optimizer = g.optimizer;
+  lp.max_iterations = g.max_iterations;
+  lp.lm_max_iterations = g.lm_max_iterations;
+  lp.rotation_eps = g.rotation_eps;
+  lp.translation_eps = g.translation_eps;
+  lp.lm_init_lambda_factor = g.lm_init_lambda_factor;
+  return lp;
+}
+
+bool same_solver_config(const pcm_config& a, const pcm_config& b) {
+  return a.model == b.model && a.optimizer == b.optimizer && a.max_iterations == b.max_iterations && a.lm_max_iterations == b.lm_max_iterations &&
+         a.rotation_eps == b.rotation_eps && a.translation_eps == b.translation_eps && a.lm_init_lambda_factor == b.lm_init_lambda_factor &&
+         a.num_neighbors == b.num_neighbors && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold;
+}
+
+int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_result* host_out, void* device_out) {
+  if (!ctxs || n <= 0 || !guesses) return PCM_ERR_INVALID_ARGUMENT;
+  pcm_ctx* c0 = ctxs[0];
+  if (!c0) return PCM_ERR_INVALID_ARGUMENT;
+  size_t max_n = 0;
+  for (int i = 0; i < n; i++) {
+    pcm_ctx* c = ctxs[i];
+    if (!c) { c0->err = "null context in batch"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (c->device != c0->device) { c0->err = "all contexts of a batch must live on one device"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (!same_solver_config(c->cfg, c0->cfg)) { c0->err = "all contexts of a batch must share the solver configuration"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (c->stream != c0->stream) {
+      // inputs of the other contexts were produced on their own streams, which are idle after set_*()
+    }
+    int rc = prepare(c);
+    if (rc != PCM_OK) { if (c != c0) c0->err = c->err; return rc; }
+    max_n = std::max(max_n, c->src.n);
+  }
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  const pcm_config& g = c0->cfg;
+  const Geom geom = pick_geom(max_n, n);
+  const LsqParams lp = lsq_params(g);
+  const KernelParams kp = kernel_params(g, geom);
+  // worst case: every outer iteration = 1 linearize + lm_max_iterations trials
+  const int max_rounds = std::max(1, g.max_iterations) * (g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT ? 1 + std::max(1, g.lm_max_iterations) : 1) + 1;
+  const size_t per_pair_partials = (size_t)geom.blocks_per_pair * kPartialStride;
+  Workspace* w = nullptr;
+  int rc = ensure_ws(c0, &w, n, per_pair_partials * n, max_rounds);
+  if (rc != PCM_OK) return rc;
+  hipStream_t st = c0->stream;
+
+  std::vector<PairDesc> descs(n);
+  for (int i = 0; i < n; i++) fill_desc(ctxs[i], &descs[i], w->d_partials + per_pair_partials * i);
+  HIPCK(c0, hipMemcpyAsync(w->d_descs, descs.data(), sizeof(PairDesc) * n, hipMemcpyHostToDevice, st));
+  HIPCK(c0, hipMemcpyAsync(w->d_guesses, guesses, sizeof(float) * 16 * n, hipMemcpyHostToDevice, st));
+  HIPCK(c0, hipMemsetAsync(w->d_active, 0, sizeof(int) * max_rounds, st));
+  launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations);
+  const bool stats_on = c0->profiling;
+  if (stats_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 4, st));
+  const bool write_planes = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;
+
+  int rounds_done = 0;
+  size_t prof_used = 0;
+  for (int r = 0; r < max_rounds; r++) {
+    if (stats_on) {
+      while (w->ev_prof.size() < prof_used + 2) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
+      HIPCK(c0, hipEventRecord(w->ev_prof[prof_used], st));
+    }
+    launch_p2plane(st, w->d_descs, w->d_states, kp, n, write_planes, stats_on ? w->d_stats : nullptr);
+    if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st)); prof_used += 2; }
+    launch_lsq_step(st, w->d_descs, w->d_states, lp, geom.blocks_per_pair, n, w->d_active + r);
+    HIPCK(c0, hipMemcpyAsync(w->h_active + r, w->d_active + r, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCK(c0, hipEventRecord(w->ev_round[r & 1], st));
+    rounds_done = r + 1;
+    if (r >= 1) {  // look one round behind so the GPU always has the next round queued
+      HIPCK(c0, hipEventSynchronize(w->ev_round[(r - 1) & 1]));
+      if (w->h_active[r - 1] == 0) break;
+    }
+  }
+  HIPCK(c0, hipGetLastError());
+  pcm_result* d_res = device_out ? static_cast<pcm_result*>(device_out) : w->d_results;
+  launch_pack_results(st, w->d_states, d_res, n);
+  std::vector<pcm_result> tmp;
+  pcm_result* h_res = host_out;
+  if (!h_res) { tmp.resize(n); h_res = tmp.data(); }
+  HIPCK(c0, hipMemcpyAsync(h_res, d_res, sizeof(pcm_result) * n, hipMemcpyDeviceToHost, st));
+  HIPCK(c0, hipStreamSynchronize(st));
+
+  if (stats_on) {
+    unsigned long long hs[4];
+    HIPCK(c0, hipMemcpy(hs, w->d_stats, sizeof(hs), hipMemcpyDeviceToHost));
+    double ms = 0.0;
+    for (size_t k = 0; k + 1 < prof_used; k += 2) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, w->ev_prof[k], w->ev_prof[k + 1]) == hipSuccess) ms += t;
+    }
+    c0->stats.linearize_ms += ms;
+    c0->stats.candidates += hs[0];
+    c0->stats.slots_probed += hs[1];
+  }
+  c0->stats.linearize_launches += (uint64_t)rounds_done;
+  uint64_t passes = 0;
+  int worst = PCM_OK;
+  for (int i = 0; i < n; i++) {
+    passes += (uint64_t)(h_res[i].num_linearize + h_res[i].num_compute_error) * ctxs[i]->src.n;
+    if (h_res[i].status != PCM_OK) worst = h_res[i].status;
+  }
+  c0->stats.point_passes += passes;
+  if (worst != PCM_OK) c0->err = "lm not converged!!";
+  return worst;
+}
+
+// one LINEARIZE or TRIAL pass at a caller-supplied pose (parity hook)
+int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPartialStride]) {
+  int rc = prepare(c);
+  if (rc != PCM_OK) return rc;
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  const Geom geom = pick_geom(c->src.n, 1);
+  const KernelParams kp = kernel_params(c->cfg, geom);
+  Workspace* w = nullptr;
+  rc = ensure_ws(c, &w, 1, (size_t)geom.blocks_per_pair * kPartialStride, 2);
+  if (rc != PCM_OK) return rc;
+  PairDesc d;
+  fill_desc(c, &d, w->d_partials);
+  PairState s;
+  float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  init_state(s, ident);
+  for (int i = 0; i < 16; i++) { s.x0[i] = T[i]; s.xi[i] = T[i]; }
+  s.mode = linearize ? MODE_LINEARIZE : MODE_TRIAL;
+  HIPCK(c, hipMemcpyAsync(w->d_descs, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipMemcpyAsync(w->d_states, &s, sizeof(s), hipMemcpyHostToDevice, c->stream));
+  launch_p2plane(c->stream, w->d_descs, w->d_states, kp, 1, true, nullptr);
+  launch_reduce_only(c->stream, w->d_descs, geom.blocks_per_pair, 1, w->d_sums);
+  HIPCK(c, hipGetLastError());
+  HIPCK(c, hipMemcpyAsync(sums, w->d_sums, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return PCM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pcm_abi_version(void) { return PCM_ABI_VERSION; }
+
+void pcm_default_config(pcm_config* cfg) {
+  if (!cfg) return;
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->model = PCM_MODEL_P2PLANE;
+  cfg->optimizer = PCM_OPT_LEVENBERG_MARQUARDT;
+  cfg->max_iterations = 64;
+  cfg->lm_max_iterations = 10;
+  cfg->rotation_eps = 2e-3;
+  cfg->translation_eps = 5e-4;
+  cfg->lm_init_lambda_factor = 1e-9;
+  cfg->voxel_resolution = 0.5f;
+  cfg->num_neighbors = 27;
+  cfg->knn = 5;
+  cfg->min_knn = 3;
+  cfg->max_range = 5.0f;
+  cfg->plane_threshold = 0.1f;
+  cfg->max_corr_dist = FLT_MAX;
+  cfg->k_correspondences = 20;
+  cfg->regularization = PCM_REG_PLANE;
+  cfg->sort_source = 0;
+}
+
+pcm_ctx* pcm_create(int device, const pcm_config* cfg) {
+  pcm_ctx* c = new (std::nothrow) pcm_ctx();
+  if (!c) return nullptr;
+  c->device = device;
+  if (cfg) c->cfg = *cfg; else pcm_default_config(&c->cfg);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    // keep the object so the caller can read the reason, but mark it unusable
+    c->err = "no such HIP device (the MI355X path has no CPU fallback)";
+    c->device = -1;
+    return c;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    c->err = "hipStreamCreate failed";
+    c->device = -1;
+    return c;
+  }
+  c->own_stream = true;
+  return c;
+}
+
+void pcm_destroy(pcm_ctx* c) {
+  if (!c) return;
+  if (c->device >= 0) {
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    c->src.release();
+    c->tgt.release();
+    c->map.release();
+    if (c->planes) hipFree(c->planes);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+const char* pcm_last_error(const pcm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+#define CHECK_CTX(c)                                                   \
+  do {                                                                 \
+    if (!(c)) return PCM_ERR_INVALID_ARGUMENT;                         \
+    if ((c)->device < 0) return PCM_ERR_HIP;                           \
+  } while (0)
+
+int pcm_get_config(const pcm_ctx* c, pcm_config* out) {
+  if (!c || !out) return PCM_ERR_INVALID_ARGUMENT;
+  *out = c->cfg;
+  return PCM_OK;
+}
+
+int pcm_set_config(pcm_ctx* c, const pcm_config* cfg) {
+  CHECK_CTX(c);
+  if (!cfg) return PCM_ERR_INVALID_ARGUMENT;
+  int rc = validate_config(c, *cfg);
+  if (rc != PCM_OK) return rc;
+  c->cfg = *cfg;
+  return PCM_OK;
+}
+
+int pcm_set_stream(pcm_ctx* c, void* hip_stream) {
+  CHECK_CTX(c);
+  if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+  c->stream = static_cast<hipStream_t>(hip_stream);
+  c->own_stream = false;
+  return PCM_OK;
+}
+
+int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes, int memory, uint64_t tag) {
+  CHECK_CTX(c);
+  if (tag != 0 && tag == c->tgt.tag && c->tgt.n == n) return PCM_OK;  // `if (target_ == cloud) return;`  fast_gicp_impl.hpp:83-85
+  int rc = set_cloud(c, &c->tgt, points, n, stride_bytes, memory, tag);
+  c->map.valid = false;
+  return rc;
+}
+
+int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes, int memory, uint64_t tag) {
+  CHECK_CTX(c);
+  if (tag != 0 && tag == c->src.tag && c->src.n == n) return PCM_OK;  // fast_gicp_impl.hpp:72-74
+  int rc = set_cloud(c, &c->src, points, n, stride_bytes, memory, tag);
+  c->src_sorted = false;
+  return rc;
+}
+
+int pcm_swap_source_and_target(pcm_ctx* c) {
+  CHECK_CTX(c);
+  std::swap(c->src, c->tgt);
+  c->map.valid = false;
+  c->src_sorted = false;
+  return PCM_OK;
+}
+
+int pcm_clear_source(pcm_ctx* c) {
+  CHECK_CTX(c);
+  c->src.n = 0; c->src.tag = 0; c->src_sorted = false;
+  return PCM_OK;
+}
+
+int pcm_clear_target(pcm_ctx* c) {
+  CHECK_CTX(c);
+  c->tgt.n = 0; c->tgt.tag = 0; c->map.valid = false;
+  return PCM_OK;
+}
+
+int pcm_align(pcm_ctx* c, const float guess[16], pcm_result* out) {
+  CHECK_CTX(c);
+  if (!guess || !out) return PCM_ERR_INVALID_ARGUMENT;
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  pcm_ctx* arr[1] = {c};
+  return align_batch_impl(arr, 1, guess, out, nullptr);
+}
+
+int pcm_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_result* host_out, void* device_out) {
+  if (!ctxs || n <= 0) return PCM_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n; i++) {
+    CHECK_CTX(ctxs[i]);
+    int rc = validate_config(ctxs[i], ctxs[i]->cfg);
+    if (rc != PCM_OK) return rc;
+  }
+  return align_batch_impl(ctxs, n, guesses, host_out, device_out);
+}
+
+int pcm_linearize(pcm_ctx* c, const double T[16], double H[36], double b[6], double* cost, int32_t* num_inliers) {
+  CHECK_CTX(c);
+  if (!T) return PCM_ERR_INVALID_ARGUMENT;
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  double s[kPartialStride];
+  rc = single_pass(c, T, true, s);
+  if (rc != PCM_OK) return rc;
+  int t = 0;
+  for (int a = 0; a < 6; a++) {
+    for (int k = a; k < 6; k++) {
+      if (H) { H[a * 6 + k] = s[t]; H[k * 6 + a] = s[t]; }
+      t++;
+    }
+  }
+  if (b) for (int a = 0; a < 6; a++) b[a] = s[21 + a];
+  if (cost) *cost = s[27];
+  if (num_inliers) *num_inliers = (int32_t)s[28];
+  return PCM_OK;
+}
+
+int pcm_compute_error(pcm_ctx* c, const double T[16], double* cost) {
+  CHECK_CTX(c);
+  if (!T || !cost) return PCM_ERR_INVALID_ARGUMENT;
+  double s[kPartialStride];
+  int rc = single_pass(c, T, false, s);
+  if (rc != PCM_OK) return rc;
+  *cost = s[27];
+  return PCM_OK;
+}
+
+int pcm_get_planes(pcm_ctx* c, float* out, size_t n) {
+  CHECK_CTX(c);
+  if (!out || n != c->src.n || !c->planes) { c->err = "pcm_get_planes: call pcm_linearize first; n must equal the source size"; return PCM_ERR_INVALID_ARGUMENT; }
+  HIPCK(c, hipMemcpy(out, c->planes, sizeof(float4) * n, hipMemcpyDeviceToHost));
+  return PCM_OK;
+}
+
+int pcm_get_stats(pcm_ctx* c, pcm_stats* out) {
+  if (!c || !out) return PCM_ERR_INVALID_ARGUMENT;
+  *out = c->stats;
+  return PCM_OK;
+}
+
+int pcm_reset_stats(pcm_ctx* c) {
+  if (!c) return PCM_ERR_INVALID_ARGUMENT;
+  const uint64_t v = c->stats.target_voxels, s = c->stats.target_slots;
+  c->stats = pcm_stats{};
+  c->stats.target_voxels = v;
+  c->stats.target_slots = s;
+  return PCM_OK;
+}
+
+int pcm_set_profiling(pcm_ctx* c, int on) {
+  if (!c) return PCM_ERR_INVALID_ARGUMENT;
+  c->profiling = on != 0;
+  return PCM_OK;
+}
+
+}  // extern "C"

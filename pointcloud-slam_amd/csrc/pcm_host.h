@@ -1,0 +1,72 @@
+// pcm_host.h -- host-side objects behind the C ABI (include/pcm_amd.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pcm_amd.h"
+#include "lsq_step.h"
+#include "pcm_device.h"
+
+namespace pcm {
+
+struct Cloud {
+  float4* d_pts = nullptr;  // compact device copy, input order
+  size_t n = 0;
+  size_t cap = 0;
+  uint64_t tag = 0;
+  void release() {
+    if (d_pts) hipFree(d_pts);
+    d_pts = nullptr; n = cap = 0; tag = 0;
+  }
+};
+
+struct TargetMap {
+  Slot* slots = nullptr;
+  float4* pts = nullptr;  // grouped by voxel
+  uint32_t cap = 0, num_voxels = 0, num_points = 0;
+  float res = 0.f, inv_res = 0.f;
+  int coord_mode = 0;
+  bool valid = false;
+  void release() {
+    if (slots) hipFree(slots);
+    if (pts) hipFree(pts);
+    slots = nullptr; pts = nullptr; cap = num_voxels = num_points = 0; valid = false;
+  }
+};
+
+int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, TargetMap* map, std::string* err);
+int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, float4* d_out, std::string* err);
+int sort_source_along_grid(hipStream_t stream, float4* d_pts, uint32_t n, float res, std::string* err);
+
+// residual-kernel launchers (p2plane.hip)
+struct LaunchGeom {
+  int npairs;
+  int blocks_per_pair;
+  int points_per_block;
+};
+void launch_p2plane(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
+                    unsigned long long* d_stats);
+void launch_lsq_step(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const LsqParams& lp, int blocks_per_pair, int npairs, int* d_active_slot);
+void launch_reduce_only(hipStream_t stream, const PairDesc* d_descs, int blocks_per_pair, int npairs, double* d_sums /* npairs x 32 */);
+void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations);
+void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
+
+}  // namespace pcm
+
+struct pcm_ctx {
+  int device = 0;
+  pcm_config cfg{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  pcm::Cloud src, tgt;
+  pcm::TargetMap map;
+  bool src_sorted = false;
+  float4* planes = nullptr;
+  size_t planes_cap = 0;
+  std::string err;
+  pcm_stats stats{};
+  bool profiling = false;
+};

@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's registration operator surface.
+
+Same names, argument meaning and call order as the reference's pybind module
+``pygicp`` (/root/reference/src/pointcloud_match/fast_gicp/src/python/main.cpp:135-215:
+``set_input_target/source``, ``align``, ``swap_source_and_target``,
+``get_final_transformation``, ``get_final_hessian`` ...) and the
+``pcl::Registration`` setters it wraps, so the parity tests read like the
+reference's gtest (src/test/gicp_test.cpp:147-201).  All compute goes through
+the C ABI of include/pcm_amd.h; nothing here touches oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+
+import numpy as np
+
+from . import capi
+
+
+@dataclasses.dataclass
+class RegistrationResult:
+    T: np.ndarray            # (4,4) float32 final_transformation_
+    T64: np.ndarray          # (4,4) float64 pose before the float cast
+    H: np.ndarray            # (6,6) final_hessian_
+    cost: float
+    iterations: int
+    converged: bool
+    num_linearize: int
+    num_compute_error: int
+    num_inliers: int
+    status: int
+
+
+def _result(r: capi.PcmResult) -> RegistrationResult:
+    return RegistrationResult(np.array(r.T[:], np.float32).reshape(4, 4), np.array(r.T64[:]).reshape(4, 4),
+                              np.array(r.H[:]).reshape(6, 6), r.cost, r.iterations, bool(r.converged),
+                              r.num_linearize, r.num_compute_error, r.num_inliers, r.status)
+
+
+def _points(a):
+    """Accept (N,>=3) float32 host arrays or torch CUDA tensors; returns (ptr, n, stride, memory, keepalive)."""
+    if hasattr(a, "data_ptr") and hasattr(a, "is_cuda"):
+        if a.dtype.__str__() != "torch.float32" or a.dim() != 2 or a.shape[1] < 3 or not a.is_contiguous():
+            raise ValueError("expected a contiguous (N,>=3) float32 tensor")
+        mem = capi.MEM_DEVICE if a.is_cuda else capi.MEM_HOST
+        return a.data_ptr(), a.shape[0], a.shape[1] * 4, mem, a
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    if arr.ndim != 2 or arr.shape[1] < 3:
+        raise ValueError("expected an (N,>=3) float32 array")
+    return arr.ctypes.data, arr.shape[0], arr.shape[1] * 4, capi.MEM_HOST, arr
+
+
+class Registration:
+    """One registration object bound to a HIP device (= one ``pcm_ctx``)."""
+
+    model = "P2PLANE"
+
+    def __init__(self, device: int = 0, **params):
+        self._L = capi.load_library()
+        cfg = capi.PcmConfig()
+        self._L.pcm_default_config(C.byref(cfg))
+        cfg.model = capi.MODEL[self.model]
+        self._cfg = cfg
+        self._h = self._L.pcm_create(device, C.byref(cfg))
+        if not self._h:
+            raise capi.PcmError(-3, "pcm_create failed")
+        self._keep = {}
+        self._last = None
+        self._set(**params)
+
+    # -- plumbing ---------------------------------------------------------
+    def _check(self, rc, allow=(capi.PCM_OK,)):
+        if rc not in allow:
+            raise capi.PcmError(rc, (self._L.pcm_last_error(self._h) or b"").decode())
+
+    def _set(self, **kw):
+        for k, v in kw.items():
+            if k == "optimizer" and isinstance(v, str):
+                v = capi.OPTIMIZER[v]
+            if k == "regularization" and isinstance(v, str):
+                v = capi.REGULARIZATION[v]
+            if not hasattr(self._cfg, k):
+                raise KeyError(k)
+            setattr(self._cfg, k, v)
+        self._check(self._L.pcm_set_config(self._h, C.byref(self._cfg)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.pcm_destroy(h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- pcl::Registration / LsqRegistration setters ------------------------
+    def set_max_iterations(self, n): self._set(max_iterations=int(n))            # setMaximumIterations
+    def set_transformation_epsilon(self, e): self._set(translation_eps=float(e))   # setTransformationEpsilon
+    def set_rotation_epsilon(self, e): self._set(rotation_eps=float(e))            # lsq_registration_impl.hpp:27-29
+    def set_initial_lambda_factor(self, f): self._set(lm_init_lambda_factor=float(f))  # :32-34
+    def set_optimizer(self, name): self._set(optimizer=name)                       # lsq_optimizer_type_
+    def set_resolution(self, r): self._set(voxel_resolution=float(r))              # fast_vgicp_impl.hpp:28-30
+    def set_num_neighbors(self, n): self._set(num_neighbors=int(n))                # setNeighborSearchMethod / ivox_nearby_type
+    def set_max_correspondence_distance(self, d): self._set(max_range=float(d), max_corr_dist=float(d))
+    def set_num_threads(self, n): pass                                              # setNumThreads: no meaning on the GPU
+    def set_stream(self, hip_stream: int): self._check(self._L.pcm_set_stream(self._h, hip_stream))
+    def set_profiling(self, on: bool): self._check(self._L.pcm_set_profiling(self._h, int(on)))
+
+    # -- inputs -------------------------------------------------------------
+    def set_input_target(self, cloud, tag: int = 0):
+        ptr, n, stride, mem, keep = _points(cloud)
+        self._check(self._L.pcm_set_target(self._h, ptr, n, stride, mem, tag))
+
+    def set_input_source(self, cloud, tag: int = 0):
+        ptr, n, stride, mem, keep = _points(cloud)
+        self._check(self._L.pcm_set_source(self._h, ptr, n, stride, mem, tag))
+
+    def swap_source_and_target(self): self._check(self._L.pcm_swap_source_and_target(self._h))
+    def clear_source(self): self._check(self._L.pcm_clear_source(self._h))
+    def clear_target(self): self._check(self._L.pcm_clear_target(self._h))
+
+    # -- compute ------------------------------------------------------------
+    def align(self, initial_guess=None) -> RegistrationResult:
+        g = np.eye(4, dtype=np.float32) if initial_guess is None else np.ascontiguousarray(initial_guess, dtype=np.float32)
+        res = capi.PcmResult()
+        self._check(self._L.pcm_align(self._h, g.ctypes.data, C.byref(res)), allow=(capi.PCM_OK, capi.PCM_ERR_NOT_CONVERGED))
+        self._last = _result(res)
+        return self._last
+
+    def evaluate_cost(self, T):
+        """LsqRegistration::evaluateCost -> (cost, H, b, num_inliers)  (lsq_registration_impl.hpp:46-49)."""
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        H = np.zeros((6, 6)); b = np.zeros(6)
+        cost = C.c_double(); inl = C.c_int32()
+        self._check(self._L.pcm_linearize(self._h, T.ctypes.data, H.ctypes.data, b.ctypes.data, C.byref(cost), C.byref(inl)))
+        return cost.value, H, b, inl.value
+
+    linearize = evaluate_cost
+
+    def compute_error(self, T) -> float:
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        cost = C.c_double()
+        self._check(self._L.pcm_compute_error(self._h, T.ctypes.data, C.byref(cost)))
+        return cost.value
+
+    def get_planes(self, n: int) -> np.ndarray:
+        """(n,4) planes fitted by the last evaluate_cost (NaN row = point not selected)."""
+        out = np.zeros((n, 4), np.float32)
+        self._check(self._L.pcm_get_planes(self._h, out.ctypes.data, n))
+        return out
+
+    def get_final_transformation(self): return self._last.T
+    def get_final_hessian(self): return self._last.H
+    def has_converged(self): return self._last.converged
+
+    def stats(self) -> dict:
+        s = capi.PcmStats()
+        self._check(self._L.pcm_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in capi.PcmStats._fields_ if k != "reserved"}
+
+    def reset_stats(self): self._check(self._L.pcm_reset_stats(self._h))
+
+
+class P2PlaneRegistration(Registration):
+    """Point-to-plane scan-to-submap ICP with jueying_lio's matcher semantics
+    (5-NN in the voxel hash -> plane fit -> n.p+d; laser_mapping.cc:592-701)
+    under fast_gicp's GN/LM loop."""
+    model = "P2PLANE"
+
+
+def align_batch(regs, guesses, device_out=None):
+    """Align a batch of independent registration objects in lock-step launches
+    (pcm_align_batch).  ``device_out``: optional device pointer (int) receiving
+    the packed ``pcm_result`` records, e.g. a tensor handed to an RCCL gather."""
+    L = capi.load_library()
+    n = len(regs)
+    g = np.ascontiguousarray(guesses, dtype=np.float32).reshape(n, 16)
+    arr = (C.c_void_p * n)(*[r.handle for r in regs])
+    out = (capi.PcmResult * n)()
+    rc = L.pcm_align_batch(arr, n, g.ctypes.data, out, device_out)
+    if rc not in (capi.PCM_OK, capi.PCM_ERR_NOT_CONVERGED):
+        raise capi.PcmError(rc, (L.pcm_last_error(regs[0].handle) or b"").decode())
+    res = [_result(out[i]) for i in range(n)]
+    for r, x in zip(regs, res):
+        r._last = x
+    return res

@@ -1,0 +1,186 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Run on the MI355X box with ``-m gpu``.
+
+Tolerances: poses within 1e-4 m / 1e-4 rad (BASELINE.json north_star); normal
+equations (H, b, cost) within 1e-5 relative; inlier counts exact.
+"""
+import numpy as np
+import pytest
+
+from helpers import HB_RTOL, POSE_TOL_M, POSE_TOL_RAD, pose_error, rel_err
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(voxel_resolution=0.5, num_neighbors=27)
+
+
+def _oracle(optimizer="GN", **kw):
+    from oracle import Oracle
+    p = dict(CFG); p.update(kw)
+    return Oracle("P2PLANE", optimizer, **p)
+
+
+def _gpu(pcm, optimizer="GN", **kw):
+    p = dict(CFG); p.update(kw)
+    return pcm.P2PlaneRegistration(0, optimizer=optimizer, **p)
+
+
+@pytest.fixture(scope="module")
+def pair10k(synth):
+    return synth.make_pair(0, 10000, 100000)   # BASELINE config 1
+
+
+def test_linearize_matches_oracle(pcm, pair10k):
+    p = pair10k
+    o = _oracle(); o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g = _gpu(pcm); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    for T in (p.guess.astype(np.float64), p.T_gt):
+        c0, H0, b0 = o.linearize(T)
+        c1, H1, b1, inl = g.evaluate_cost(T)
+        assert inl == o.num_inliers
+        assert rel_err(H1, H0) < HB_RTOL
+        assert rel_err(b1, b0) < HB_RTOL
+        assert abs(c1 - c0) <= HB_RTOL * abs(c0)
+        # compute_error re-uses the planes of the linearize above
+        T2 = T.copy(); T2[:3, 3] += [0.01, -0.02, 0.005]
+        assert abs(g.compute_error(T2) - o.compute_error(T2)) <= HB_RTOL * abs(o.compute_error(T2))
+
+
+@pytest.mark.parametrize("nn", [1, 7, 19, 27])
+def test_neighbor_modes(pcm, pair10k, nn):
+    p = pair10k
+    o = _oracle(num_neighbors=nn); o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g = _gpu(pcm, num_neighbors=nn); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    c0, H0, b0 = o.linearize(p.T_gt)
+    c1, H1, b1, inl = g.evaluate_cost(p.T_gt)
+    assert inl == o.num_inliers
+    assert rel_err(H1, H0) < HB_RTOL and rel_err(b1, b0) < HB_RTOL
+
+
+@pytest.mark.parametrize("optimizer", ["GN", "LM"])
+def test_align_matches_oracle(pcm, pair10k, optimizer):
+    from oracle.loader import result_T
+    p = pair10k
+    o = _oracle(optimizer); o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g = _gpu(pcm, optimizer); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    ro = o.align(p.guess)
+    rg = g.align(p.guess)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+    assert rg.iterations == ro.iterations and rg.converged == bool(ro.converged)
+    assert rg.num_linearize == ro.num_linearize and rg.num_compute_error == ro.num_compute_error
+    assert rg.num_inliers == ro.num_inliers
+    assert rel_err(rg.H, np.array(ro.H[:]).reshape(6, 6)) < 1e-4
+    assert np.allclose(rg.T, rg.T64.astype(np.float32))   # final_transformation_ = x0.cast<float>()
+
+
+def test_known_answer_corner(pcm, synth):
+    sc, sm, T = synth.corner_scene(5000, 60000, seed=1)
+    g = _gpu(pcm, "LM"); g.set_input_target(sm); g.set_input_source(sc)
+    r = g.align()
+    dt, dr = pose_error(T, r.T64)
+    assert r.converged and dt < 1e-5 and dr < 1e-5
+
+
+def test_sorted_source_same_pose(pcm, pair10k):
+    """sort_source only permutes the scan: same normal equations up to summation order."""
+    p = pair10k
+    a = _gpu(pcm); a.set_input_target(p.submap); a.set_input_source(p.scan)
+    b = _gpu(pcm, sort_source=1); b.set_input_target(p.submap); b.set_input_source(p.scan)
+    c0, H0, b0, i0 = a.evaluate_cost(p.T_gt)
+    c1, H1, b1, i1 = b.evaluate_cost(p.T_gt)
+    assert i0 == i1 and rel_err(H1, H0) < 1e-12 and rel_err(b1, b0) < 1e-10
+    ra, rb = a.align(p.guess), b.align(p.guess)
+    dt, dr = pose_error(ra.T64, rb.T64)
+    assert dt < 1e-9 and dr < 1e-9
+
+
+def test_batch_matches_single(pcm, synth):
+    """pcm_align_batch over ragged, independent pairs == one pcm_align per pair."""
+    pairs = [synth.make_pair(10 + i, 4000 + 1500 * i, 40000 + 9000 * i) for i in range(4)]
+    regs = []
+    for p in pairs:
+        g = _gpu(pcm, "LM"); g.set_input_target(p.submap); g.set_input_source(p.scan); regs.append(g)
+    singles = [g.align(p.guess) for g, p in zip(regs, pairs)]
+    batch = pcm.align_batch(regs, np.stack([p.guess for p in pairs]))
+    for s, b in zip(singles, batch):
+        assert np.array_equal(s.T64, b.T64)
+        assert s.iterations == b.iterations and s.num_linearize == b.num_linearize
+
+
+def test_call_order_scenarios(pcm, pair10k):
+    """The four call orders of the reference's AlignmentTest (gicp_test.cpp:157-200),
+    here on a scene where source and target can trade places: two samplings of
+    one scene.  Pins the setInput*/swap caching semantics."""
+    from oracle.loader import result_T
+    p = pair10k
+    world_scan = (p.scan[:, :3] @ p.T_gt[:3, :3].T + p.T_gt[:3, 3]).astype(np.float32)
+    A = np.ascontiguousarray(p.submap[:, :3]); B = np.ascontiguousarray(world_scan)
+    T0 = np.eye(4, dtype=np.float32); T0[:3, 3] = [0.05, -0.03, 0.02]
+    g = _gpu(pcm, "LM")
+    g.set_input_target(A); g.set_input_source(B)
+    fwd = g.align(T0)
+    o = _oracle("LM"); o.set_input_target(A); o.set_input_source(B)
+    dt, dr = pose_error(result_T(o.align(T0)), fwd.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+    # swap + set source: source:=A then swap -> target=A; set source B
+    g2 = _gpu(pcm, "LM")
+    g2.set_input_source(A); g2.swap_source_and_target(); g2.set_input_source(B)
+    assert np.array_equal(g2.align(T0).T64, fwd.T64)
+    # swap + set target
+    g3 = _gpu(pcm, "LM")
+    g3.set_input_target(B); g3.swap_source_and_target(); g3.set_input_target(A)
+    assert np.array_equal(g3.align(T0).T64, fwd.T64)
+    # pointer-identity cache: same tag -> no-op even if the buffer content differs
+    g4 = _gpu(pcm, "LM")
+    g4.set_input_target(A, tag=1234); g4.set_input_source(B, tag=99)
+    g4.set_input_target(A[: len(A)].copy() * 0 + 1.0, tag=1234)
+    assert np.array_equal(g4.align(T0).T64, fwd.T64)
+
+
+def test_edge_cases(pcm, synth):
+    g = _gpu(pcm)
+    with pytest.raises(pcm.PcmError):          # align before inputs
+        g.align()
+    sc, sm, T = synth.corner_scene(50, 2000, seed=3)
+    g.set_input_target(sm)
+    with pytest.raises(pcm.PcmError):
+        g.align()
+    g.set_input_source(sc)
+    g.clear_source()
+    with pytest.raises(pcm.PcmError):
+        g.align()
+    # a scan that matches nothing: zero inliers, H = 0, pose stays finite
+    far = np.full((64, 3), 1.0e4, np.float32) + np.random.default_rng(0).normal(size=(64, 3)).astype(np.float32)
+    g.set_input_source(far)
+    c, H, b, inl = g.evaluate_cost(np.eye(4))
+    assert inl == 0 and c == 0.0 and not H.any() and not b.any()
+    # tiny clouds (fewer than 5 map points in reach -> the double-precision plane path)
+    o = _oracle(); o.set_input_target(sm[:7]); o.set_input_source(sc)
+    g.set_input_target(sm[:7]); g.set_input_source(sc)
+    c0, H0, b0 = o.linearize(T)
+    c1, H1, b1, inl = g.evaluate_cost(T)
+    assert inl == o.num_inliers
+    if inl:
+        assert rel_err(H1, H0) < HB_RTOL
+    with pytest.raises(pcm.PcmError):
+        pcm.P2PlaneRegistration(0, num_neighbors=5)
+    with pytest.raises(pcm.PcmError):
+        pcm.P2PlaneRegistration(0, voxel_resolution=0.0)
+
+
+def test_strided_and_device_inputs(pcm, pair10k):
+    """PointXYZI-like 32-byte records and device-resident buffers give the same map."""
+    import torch
+    p = pair10k
+    g = _gpu(pcm); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    ref = g.evaluate_cost(p.T_gt)
+    wide_t = np.zeros((len(p.submap), 8), np.float32); wide_t[:, :3] = p.submap[:, :3]; wide_t[:, 3:] = 7.0
+    wide_s = np.zeros((len(p.scan), 12), np.float32); wide_s[:, :3] = p.scan[:, :3]
+    g2 = _gpu(pcm); g2.set_input_target(wide_t); g2.set_input_source(wide_s)
+    got = g2.evaluate_cost(p.T_gt)
+    assert got[3] == ref[3] and np.array_equal(got[1], ref[1])
+    g3 = _gpu(pcm)
+    g3.set_input_target(torch.from_numpy(wide_t).cuda()); g3.set_input_source(torch.from_numpy(p.scan).cuda())
+    got = g3.evaluate_cost(p.T_gt)
+    assert got[3] == ref[3] and np.array_equal(got[1], ref[1])
