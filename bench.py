@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- scan registrations/sec on MI355X (BASELINE.json metric).
+
+One *step* = one pass of the hot path over one batch: every rank aligns its
+shard of independent (100k-pt Livox-shaped scan, 1M-pt submap) pairs with the
+point-to-plane model -- voxel-hash 5-NN, plane fit, J^T J / J^T r reduction and
+the Gauss-Newton loop to convergence -- through the C ABI (pcm_align_batch),
+followed by the RCCL all-gather of the solved poses when N > 1.  Inputs are
+resident in HBM and the submap voxel hashes are built before the timed region
+(the reference's `100times_reuse` protocol, fast_gicp/src/align.cpp:51-104);
+the cold rate (hash build included) is reported next to it.
+
+Prints ONE JSON line (rank 0).  Launch for N>1 with torch.distributed.run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+SLOT_BYTES = 16                # hash slot  
+POINT_BYTES = 16               # float4 query / map point
+
+
+def _gen_pair(args):
+    pair_id, n_scan, n_map = args
+    import importlib
+    synth = importlib.import_module("pointcloud-slam_amd.synth")
+    p = synth.make_pair(pair_id, n_scan, n_map)
+    return p.scan, p.submap, p.guess, p.T_gt
+
+
+def generate_pairs(ids, n_scan, n_map, workers):
+    """Seeded synthetic pairs, generated on host cores BEFORE anything touches the GPU."""
+    jobs = [(i, n_scan, n_map) for i in ids]
+    if workers <= 1 or len(jobs) == 1:
+        return [_gen_pair(j) for j in jobs]
+    with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+        return pool.map(_gen_pair, jobs)
+
+
+def cpu_baseline(pairs, cfg, budget_s):
+    """Oracle (CPU restatement of the reference path) timed on this host's cores on
+    a bounded sample of the same workload.  A reported baseline, not the target."""
+    from oracle import Oracle
+    threads = min(len(os.sched_getaffinity(0)), 16)   # the GPU box's CPU share for one GPU
+    t_all = time.perf_counter()
+    n_done, t_align, iters = 0, 0.0, []
+    for scan, submap, guess, _ in pairs:
+        o = Oracle("P2PLANE", cfg["optimizer"], voxel_resolution=cfg["voxel_resolution"], num_neighbors=cfg["num_neighbors"],
+                   max_iterations=cfg["max_iterations"], num_threads=threads)
+        o.set_input_target(submap)
+        o.set_input_source(scan)
+        o.linearize(np.asarray(guess, np.float64))       # builds the target voxel map (excluded, like the GPU number)
+        t0 = time.perf_counter()
+        r = o.align(guess)
+        t_align += time.perf_counter() - t0
+        iters.append(r.num_linearize)
+        n_done += 1
+        if time.perf_counter() - t_all > budget_s:
+            break
+    return {"value": n_done / t_align, "unit": "registrations/s", "cores": threads, "kind": "port",
+            "sample": "%d of the rank-0 pairs, oracle/ OpenMP restatement, target map prebuilt, mean %.1f linearize passes" % (n_done, float(np.mean(iters)))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-gpu", type=int, default=16)
+    ap.add_argument("--scan-points", type=int, default=100000)
+    ap.add_argument("--map-points", type=int, default=1000000)
+    ap.add_argument("--optimizer", default="GN", choices=["GN", "LM"])
+    ap.add_argument("--max-iterations", type=int, default=64)
+    ap.add_argument("--sort-source", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--gen-workers", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+
+    cfg = dict(optimizer=args.optimizer, voxel_resolution=0.5, num_neighbors=27, max_iterations=args.max_iterations)
+
+    # ---- inputs (host), before the GPU is touched so that fork() is safe -------------------------
+    ncpu = min(len(os.sched_getaffinity(0)), 16 * max(1, world))
+    workers = args.gen_workers or max(1, min(ncpu // max(1, min(world, 8)), 16))
+    ids = [rank * args.pairs_per_gpu + i for i in range(args.pairs_per_gpu)]
+    t0 = time.perf_counter()
+    pairs = generate_pairs(ids, args.scan_points, args.map_points, workers)
+    t_gen = time.perf_counter() - t0
+
+    import torch
+    import torch.distributed as dist
+    import pointcloud_slam_amd as pcm
+    from pointcloud_slam_amd import capi
+    import ctypes
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+
+    # ---- residency: scans + submaps in HBM, voxel hashes built ------------------------------------
+    regs, guesses = [], []
+    d_inputs = []
+    for scan, submap, guess, _ in pairs:
+        d_scan = torch.from_numpy(scan).to(dev)
+        d_map = torch.from_numpy(submap).to(dev)
+        d_inputs.append((d_scan, d_map))
+        r = pcm.P2PlaneRegistration(local_rank, optimizer=args.optimizer, voxel_resolution=cfg["voxel_resolution"],
+                                    num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source)
+        r.set_input_target(d_map)
+        r.set_input_source(d_scan)
+        regs.append(r)
+        guesses.append(guess)
+    guesses = np.stack(guesses)
+    n_local = len(regs)
+    rec = ctypes.sizeof(capi.PcmResult)
+    d_results = torch.zeros(n_local * rec, dtype=torch.uint8, device=dev)
+    d_gather = torch.zeros(world * n_local * rec, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        res = pcm.align_batch(regs, guesses, device_out=d_results.data_ptr())
+        if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per batch)
+            dist.all_gather_into_tensor(d_gather, d_results)
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # cold pass: includes voxel-hash build + scan re-ordering (lazy on first align)
+    fence()
+    t0 = time.perf_counter()
+    res = step()
+    fence()
+    t_cold = time.perf_counter() - t0
+
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+
+    regs[0].reset_stats()
+    regs[0].set_profiling(1)         # HIP events around every residual launch, on the launch stream
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = regs[0].stats()
+    regs[0].set_profiling(0)
+
+    t = torch.tensor([elapsed, t_cold], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, t_cold = float(t[0]), float(t[1])
+
+    # counters pass (untimed): candidates / probes per point for the algorithmic-byte model
+    regs[0].reset_stats()
+    regs[0].set_profiling(3)
+    step()
+    sc = regs[0].stats()
+    regs[0].set_profiling(0)
+    kbar = sc["candidates"] / max(1, sc["point_passes"])
+    probes = sc["slots_probed"] / max(1, sc["point_passes"])
+
+    total_regs = args.steps * n_local * world
+    value = total_regs / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # roofline of the dominant kernel (k_p2plane): algorithmic bytes per point-iteration
+    # = query float4 + 27 hash slots + K-bar candidate float4s  (SURVEY.md §8d, P2PLANE exact 5-NN row)
+    b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
+    launches = max(1, st["linearize_launches"])
+    bytes_per_launch = st["point_passes"] * b_pi / launches
+    avg_launch_ms = st["linearize_ms"] / launches
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("workload_key") == "%d_%d_%d_%s" % (args.scan_points, args.map_points, n_local, args.optimizer):
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        iters = [r.num_linearize for r in res]
+        out = {
+            "metric": "scan registrations/sec (100k-pt scan vs 1M-pt submap)",
+            "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 geometry / f64 accumulate", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence)"
+                                   % (args.scan_points, args.map_points, args.optimizer),
+                       "pairs_per_gpu": n_local, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
+                       "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), RCCL all_gather of poses" % world,
+                       "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
+                       "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_p2plane", "avg_launch_ms": avg_launch_ms,
+                         "algorithmic_bytes_per_point_pass": b_pi, "candidates_per_point": kbar, "slots_probed_per_point": probes,
+                         "point_passes_per_launch": st["point_passes"] / launches},
+        }
+        if args.cpu_seconds > 0 and world >= 1:
+            out["cpu_baseline"] = cpu_baseline(pairs, cfg, args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

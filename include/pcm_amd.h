@@ -167,9 +167,10 @@ int pcm_get_planes(pcm_ctx *ctx, float *out, size_t n);
  * pcm_result records, e.g. the buffer handed to an RCCL all_gather) may be NULL. */
 int pcm_align_batch(pcm_ctx *const *ctxs, int n, const float *guesses, pcm_result *host_out, void *device_out);
 
-/* profiling on: residual launches are bracketed by HIP events and the kNN
- * candidate / probe counters are collected (adds a few atomics per workgroup) */
-int pcm_set_profiling(pcm_ctx *ctx, int on);
+/* profiling flags: bit0 = bracket every residual launch with HIP events on the
+ * launch stream (pcm_stats.linearize_ms); bit1 = collect the kNN candidate /
+ * probe counters (slower kernel variant; use in an untimed pass) */
+int pcm_set_profiling(pcm_ctx *ctx, int flags);
 int pcm_get_stats(pcm_ctx *ctx, pcm_stats *out);
 int pcm_reset_stats(pcm_ctx *ctx);
 int pcm_abi_version(void);

@@ -238,8 +238,9 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   HIPCK(c0, hipMemcpyAsync(w->d_guesses, guesses, sizeof(float) * 16 * n, hipMemcpyHostToDevice, st));
   HIPCK(c0, hipMemsetAsync(w->d_active, 0, sizeof(int) * max_rounds, st));
   launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations);
-  const bool stats_on = c0->profiling;
-  if (stats_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 4, st));
+  const bool stats_on = (c0->profiling & 1) != 0;      // HIP events around the residual launches
+  const bool counters_on = (c0->profiling & 2) != 0;   // kNN candidate / probe counters (slower kernel variant)
+  if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 4, st));
   const bool write_planes = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;
 
   int rounds_done = 0;
@@ -249,7 +250,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       while (w->ev_prof.size() < prof_used + 2) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
       HIPCK(c0, hipEventRecord(w->ev_prof[prof_used], st));
     }
-    launch_p2plane(st, w->d_descs, w->d_states, kp, n, write_planes, stats_on ? w->d_stats : nullptr);
+    launch_p2plane(st, w->d_descs, w->d_states, kp, n, write_planes, counters_on ? w->d_stats : nullptr);
     if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st)); prof_used += 2; }
     launch_lsq_step(st, w->d_descs, w->d_states, lp, geom.blocks_per_pair, n, w->d_active + r);
     HIPCK(c0, hipMemcpyAsync(w->h_active + r, w->d_active + r, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -269,17 +270,19 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   HIPCK(c0, hipMemcpyAsync(h_res, d_res, sizeof(pcm_result) * n, hipMemcpyDeviceToHost, st));
   HIPCK(c0, hipStreamSynchronize(st));
 
-  if (stats_on) {
+  if (counters_on) {
     unsigned long long hs[4];
     HIPCK(c0, hipMemcpy(hs, w->d_stats, sizeof(hs), hipMemcpyDeviceToHost));
+    c0->stats.candidates += hs[0];
+    c0->stats.slots_probed += hs[1];
+  }
+  if (stats_on) {
     double ms = 0.0;
     for (size_t k = 0; k + 1 < prof_used; k += 2) {
       float t = 0.f;
       if (hipEventElapsedTime(&t, w->ev_prof[k], w->ev_prof[k + 1]) == hipSuccess) ms += t;
     }
     c0->stats.linearize_ms += ms;
-    c0->stats.candidates += hs[0];
-    c0->stats.slots_probed += hs[1];
   }
   c0->stats.linearize_launches += (uint64_t)rounds_done;
   uint64_t passes = 0;
@@ -524,7 +527,7 @@ int pcm_reset_stats(pcm_ctx* c) {
 
 int pcm_set_profiling(pcm_ctx* c, int on) {
   if (!c) return PCM_ERR_INVALID_ARGUMENT;
-  c->profiling = on != 0;
+  c->profiling = on;
   return PCM_OK;
 }
 

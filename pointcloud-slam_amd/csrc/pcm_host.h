@@ -68,5 +68,5 @@ struct pcm_ctx {
   size_t planes_cap = 0;
   std::string err;
   pcm_stats stats{};
-  bool profiling = false;
+  int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };

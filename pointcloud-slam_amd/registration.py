@@ -105,7 +105,7 @@ class Registration:
     def set_max_correspondence_distance(self, d): self._set(max_range=float(d), max_corr_dist=float(d))
     def set_num_threads(self, n): pass                                              # setNumThreads: no meaning on the GPU
     def set_stream(self, hip_stream: int): self._check(self._L.pcm_set_stream(self._h, hip_stream))
-    def set_profiling(self, on: bool): self._check(self._L.pcm_set_profiling(self._h, int(on)))
+    def set_profiling(self, flags: int): self._check(self._L.pcm_set_profiling(self._h, int(flags)))
 
     # -- inputs -------------------------------------------------------------
     def set_input_target(self, cloud, tag: int = 0):

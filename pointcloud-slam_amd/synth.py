@@ -50,21 +50,24 @@ class Scene:
         return parts
 
 
-def make_scene(seed: int, scale: float, n_boxes: int = 40, n_cyls: int = 10) -> Scene:
+def make_scene(seed: int, scale: float, n_boxes: int = 160, n_cyls: int = 30) -> Scene:
     rng = np.random.default_rng(seed)
     lx, ly = 4.0 * scale, 3.0 * scale
-    wall_h = 0.3 * scale + 2.0
+    wall_h = 0.1 * scale + 2.0
     boxes = []
     for _ in range(n_boxes):
-        sx, sy = rng.uniform(0.15, 0.5, 2) * scale
-        sz = rng.uniform(0.1, 0.45) * scale + 0.5
+        # many small "buildings / containers / vehicles": vertical structure within
+        # ~10-20 m of any sensor position keeps yaw and the horizontal translation
+        # observable (a scan that sees only ground is degenerate for any ICP)
+        sx, sy = rng.uniform(0.04, 0.16, 2) * scale
+        sz = rng.uniform(0.03, 0.15) * scale + 0.5
         cx = rng.uniform(0.05 * lx + sx / 2, 0.95 * lx - sx / 2)
         cy = rng.uniform(0.05 * ly + sy / 2, 0.95 * ly - sy / 2)
         boxes.append([cx - sx / 2, cy - sy / 2, 0.0, cx + sx / 2, cy + sy / 2, sz])
     cyls = []
     for _ in range(n_cyls):
-        r = rng.uniform(0.02, 0.06) * scale + 0.1
-        cyls.append([rng.uniform(0.1 * lx, 0.9 * lx), rng.uniform(0.1 * ly, 0.9 * ly), r, rng.uniform(0.2, 0.5) * scale + 1.0])
+        r = rng.uniform(0.004, 0.012) * scale + 0.1
+        cyls.append([rng.uniform(0.1 * lx, 0.9 * lx), rng.uniform(0.1 * ly, 0.9 * ly), r, rng.uniform(0.05, 0.15) * scale + 1.0])
     return Scene(lx, ly, wall_h, np.asarray(boxes, dtype=np.float64).reshape(-1, 6), np.asarray(cyls, dtype=np.float64).reshape(-1, 4))
 
 
@@ -170,7 +173,7 @@ def rosette_dirs(n: int, seed: int):
     phi = 2.0 * math.pi * (17.0 * t + 0.013 * line) + rng.uniform(0, 2 * math.pi)
     rho = np.cos(math.pi * math.sqrt(2.0) * 23.0 * t + 0.31 * line)   # irrational petal ratio
     az = np.deg2rad(FOV_H_DEG / 2) * rho * np.cos(phi)
-    el = np.deg2rad(FOV_V_DEG / 2) * rho * np.sin(phi) - np.deg2rad(8.0)
+    el = np.deg2rad(FOV_V_DEG / 2) * rho * np.sin(phi)
     d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
     offset_time = (t * FRAME_MS * 1e6).astype(np.uint32)
     return d, offset_time, line
@@ -251,13 +254,15 @@ def livox_scan(scene: Scene, T_wb: np.ndarray, n_points: int, seed: int, max_ran
 
 
 def perturb_pose(T: np.ndarray, seed: int, dt: float = 0.2, drot_deg: float = 3.0) -> np.ndarray:
-    """Initial guess: ground truth perturbed by U(-dt,dt) m and U(-drot,drot) deg per axis."""
+    """Initial guess: ground truth perturbed by U(-dt,dt) m and U(-drot,drot) deg per
+    axis, applied in the SENSOR frame (T @ D): an odometry-style error about the
+    sensor, not a rotation about the far-away world origin."""
     rng = np.random.default_rng(seed)
     a = np.deg2rad(rng.uniform(-drot_deg, drot_deg, 3))
     D = np.eye(4)
     D[:3, :3] = rot_xyz(*a)
     D[:3, 3] = rng.uniform(-dt, dt, 3)
-    return D @ T
+    return T @ D
 
 
 @dataclasses.dataclass
