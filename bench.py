@@ -136,6 +136,10 @@ def main():
     d_gather = torch.zeros(world * n_local * rec, dtype=torch.uint8, device=dev) if world > 1 else None
 
     def step():
+        # a registration starts from a NEW scan: hand every object its (HBM-resident)
+        # scan again, so the on-device Morton re-ordering is inside the timed step
+        for r, (d_scan, _) in zip(regs, d_inputs):
+            r.set_input_source(d_scan)
         res = pcm.align_batch(regs, guesses, device_out=d_results.data_ptr())
         if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per batch)
             dist.all_gather_into_tensor(d_gather, d_results)
@@ -186,7 +190,7 @@ def main():
     value = total_regs / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # roofline of the dominant kernel (k_p2plane): algorithmic bytes per point-iteration
+    # roofline of the dominant kernel (k_corr_search): algorithmic bytes per point-iteration
     # = query float4 + 27 hash slots + K-bar candidate float4s  (SURVEY.md §8d, P2PLANE exact 5-NN row)
     b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
     launches = max(1, st["linearize_launches"])
@@ -219,9 +223,11 @@ def main():
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_p2plane", "avg_launch_ms": avg_launch_ms,
+                         "traffic": traffic, "kernel": "k_corr_search", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_point_pass": b_pi, "candidates_per_point": kbar, "slots_probed_per_point": probes,
-                         "point_passes_per_launch": st["point_passes"] / launches},
+                         "point_passes_per_launch": st["point_passes"] / launches,
+                         "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]),
+                         "residual_kernel_avg_ms": st["residual_ms"] / launches},
         }
         if args.cpu_seconds > 0 and world >= 1:
             out["cpu_baseline"] = cpu_baseline(pairs, cfg, args.cpu_seconds)

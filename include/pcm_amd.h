@@ -87,9 +87,12 @@ typedef struct pcm_config {
   float max_corr_dist;           /* corr_dist_threshold_ FLT_MAX  impl/fast_gicp_impl.hpp:18 */
   int32_t k_correspondences;     /* 20  impl/fast_gicp_impl.hpp:16 */
   int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
-  int32_t sort_source;           /* 1: order the scan along the voxel grid on device (speed only) */
-  int32_t reserved[7];
+  int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
+  int32_t flags;                 /* PCM_FLAG_* (speed / debugging only, never changes a result) */
+  int32_t reserved[6];
 } pcm_config;
+
+#define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
 
 /* out-parameters of align(): getFinalTransformation / hasConverged /
  * getFinalHessian / nr_iterations_  (lsq_registration_impl.hpp:40-79) */
@@ -115,7 +118,10 @@ typedef struct pcm_stats {
   double linearize_ms;           /* HIP-event time of those launches on the context stream */
   uint64_t target_voxels;        /* occupied voxels of the current target */
   uint64_t target_slots;         /* hash-table capacity */
-  uint64_t reserved[4];
+  uint64_t tiles;                /* 256-point tiles searched (counter passes only) */
+  uint64_t tiles_lds_grid;       /* ... whose voxel box fitted the LDS grid */
+  uint64_t tiles_lds_points;     /* ... whose map points were staged through LDS as well */
+  double residual_ms;            /* HIP-event time of the residual/reduction launches */
 } pcm_stats;
 
 typedef struct pcm_ctx pcm_ctx;

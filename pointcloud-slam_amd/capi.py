@@ -38,7 +38,8 @@ class PcmConfig(C.Structure):
                 ("voxel_resolution", C.c_float), ("num_neighbors", C.c_int32), ("knn", C.c_int32),
                 ("min_knn", C.c_int32), ("max_range", C.c_float), ("plane_threshold", C.c_float),
                 ("max_corr_dist", C.c_float), ("k_correspondences", C.c_int32),
-                ("regularization", C.c_int32), ("sort_source", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("regularization", C.c_int32), ("sort_source", C.c_int32), ("flags", C.c_int32),
+                ("reserved", C.c_int32 * 6)]
 
 
 class PcmResult(C.Structure):
@@ -51,7 +52,8 @@ class PcmResult(C.Structure):
 class PcmStats(C.Structure):
     _fields_ = [("linearize_launches", C.c_uint64), ("point_passes", C.c_uint64),
                 ("candidates", C.c_uint64), ("slots_probed", C.c_uint64), ("linearize_ms", C.c_double),
-                ("target_voxels", C.c_uint64), ("target_slots", C.c_uint64), ("reserved", C.c_uint64 * 4)]
+                ("target_voxels", C.c_uint64), ("target_slots", C.c_uint64), ("tiles", C.c_uint64),
+                ("tiles_lds_grid", C.c_uint64), ("tiles_lds_points", C.c_uint64), ("residual_ms", C.c_double)]
 
 
 def library_path() -> str:

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -144,19 +145,21 @@ int prepare(pcm_ctx* c) {
 }
 
 struct Geom {
-  int blocks_per_pair;
+  int blocks_per_pair;   // residual/reduction kernel
   int points_per_block;
+  int tiles_per_pair;    // correspondence-search kernel (256-point tiles)
 };
 
 Geom pick_geom(size_t max_n, int npairs) {
-  // aim at >= ~4096 workgroups in flight over the 256 CUs; each lane then
-  // amortises the 29-value wave reduction over several points
+  // residual kernel: streaming 32 B/point; each lane amortises the 29-value wave
+  // reduction over several points, but keep >= ~1024 workgroups in flight
   size_t total = max_n * (size_t)npairs;
-  size_t ppb = (total / 4096 + 255) / 256 * 256;
+  size_t ppb = (total / 1024 + 255) / 256 * 256;
   ppb = std::min<size_t>(std::max<size_t>(ppb, 256), 2048);
   Geom g;
   g.points_per_block = (int)ppb;
   g.blocks_per_pair = (int)((max_n + ppb - 1) / ppb);
+  g.tiles_per_pair = (int)((max_n + 255) / 256);
   return g;
 }
 
@@ -178,10 +181,17 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.num_neighbors = g.num_neighbors;
   kp.knn = g.knn;
   kp.min_knn = g.min_knn;
-  kp.max_range_sq = (double)g.max_range * (double)g.max_range;
+  {  // d2 < fl  <=>  double(d2) < max_range^2  when fl is the smallest float >= max_range^2
+    const double m2 = (double)g.max_range * (double)g.max_range;
+    float fl = (float)m2;
+    if ((double)fl < m2) fl = nextafterf(fl, INFINITY);
+    kp.max_range_sq = fl;
+  }
   kp.plane_threshold = g.plane_threshold;
   kp.blocks_per_pair = geom.blocks_per_pair;
   kp.points_per_block = geom.points_per_block;
+  kp.tiles_per_pair = geom.tiles_per_pair;
+  kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
   return kp;
 }
 
@@ -199,7 +209,7 @@ LsqParams lsq_params(const pcm_config& g) {
 bool same_solver_config(const pcm_config& a, const pcm_config& b) {
   return a.model == b.model && a.optimizer == b.optimizer && a.max_iterations == b.max_iterations && a.lm_max_iterations == b.lm_max_iterations &&
          a.rotation_eps == b.rotation_eps && a.translation_eps == b.translation_eps && a.lm_init_lambda_factor == b.lm_init_lambda_factor &&
-         a.num_neighbors == b.num_neighbors && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold;
+         a.num_neighbors == b.num_neighbors && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold && a.flags == b.flags;
 }
 
 int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_result* host_out, void* device_out) {
@@ -241,17 +251,19 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   const bool stats_on = (c0->profiling & 1) != 0;      // HIP events around the residual launches
   const bool counters_on = (c0->profiling & 2) != 0;   // kNN candidate / probe counters (slower kernel variant)
   if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 4, st));
-  const bool write_planes = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;
+  const bool write_sel = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;  // trial passes re-use the selected set
 
   int rounds_done = 0;
   size_t prof_used = 0;
   for (int r = 0; r < max_rounds; r++) {
     if (stats_on) {
-      while (w->ev_prof.size() < prof_used + 2) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
+      while (w->ev_prof.size() < prof_used + 3) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
       HIPCK(c0, hipEventRecord(w->ev_prof[prof_used], st));
     }
-    launch_p2plane(st, w->d_descs, w->d_states, kp, n, write_planes, counters_on ? w->d_stats : nullptr);
-    if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st)); prof_used += 2; }
+    launch_corr_search(st, w->d_descs, w->d_states, kp, n, counters_on ? w->d_stats : nullptr);
+    if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
+    launch_residual(st, w->d_descs, w->d_states, kp, n, write_sel);
+    if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st)); prof_used += 3; }
     launch_lsq_step(st, w->d_descs, w->d_states, lp, geom.blocks_per_pair, n, w->d_active + r);
     HIPCK(c0, hipMemcpyAsync(w->h_active + r, w->d_active + r, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCK(c0, hipEventRecord(w->ev_round[r & 1], st));
@@ -275,14 +287,19 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     HIPCK(c0, hipMemcpy(hs, w->d_stats, sizeof(hs), hipMemcpyDeviceToHost));
     c0->stats.candidates += hs[0];
     c0->stats.slots_probed += hs[1];
+    c0->stats.tiles += hs[3];
+    c0->stats.tiles_lds_grid += hs[2];
+    c0->stats.tiles_lds_points += hs[2];
   }
   if (stats_on) {
-    double ms = 0.0;
-    for (size_t k = 0; k + 1 < prof_used; k += 2) {
+    double ms = 0.0, ms2 = 0.0;
+    for (size_t k = 0; k + 2 < prof_used + 1; k += 3) {
       float t = 0.f;
       if (hipEventElapsedTime(&t, w->ev_prof[k], w->ev_prof[k + 1]) == hipSuccess) ms += t;
+      if (hipEventElapsedTime(&t, w->ev_prof[k + 1], w->ev_prof[k + 2]) == hipSuccess) ms2 += t;
     }
     c0->stats.linearize_ms += ms;
+    c0->stats.residual_ms += ms2;
   }
   c0->stats.linearize_launches += (uint64_t)rounds_done;
   uint64_t passes = 0;
@@ -315,7 +332,8 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   s.mode = linearize ? MODE_LINEARIZE : MODE_TRIAL;
   HIPCK(c, hipMemcpyAsync(w->d_descs, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
   HIPCK(c, hipMemcpyAsync(w->d_states, &s, sizeof(s), hipMemcpyHostToDevice, c->stream));
-  launch_p2plane(c->stream, w->d_descs, w->d_states, kp, 1, true, nullptr);
+  if (linearize) launch_corr_search(c->stream, w->d_descs, w->d_states, kp, 1, nullptr);
+  launch_residual(c->stream, w->d_descs, w->d_states, kp, 1, true);
   launch_reduce_only(c->stream, w->d_descs, geom.blocks_per_pair, 1, w->d_sums);
   HIPCK(c, hipGetLastError());
   HIPCK(c, hipMemcpyAsync(sums, w->d_sums, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, c->stream));
@@ -348,7 +366,7 @@ void pcm_default_config(pcm_config* cfg) {
   cfg->max_corr_dist = FLT_MAX;
   cfg->k_correspondences = 20;
   cfg->regularization = PCM_REG_PLANE;
-  cfg->sort_source = 0;
+  cfg->sort_source = 1;
 }
 
 pcm_ctx* pcm_create(int device, const pcm_config* cfg) {

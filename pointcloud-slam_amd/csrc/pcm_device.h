@@ -81,10 +81,12 @@ struct KernelParams {
   int32_t num_neighbors;
   int32_t knn;
   int32_t min_knn;
-  double max_range_sq;
+  float max_range_sq;         // smallest float >= max_range^2 (see best_offer)
   float plane_threshold;
-  int32_t blocks_per_pair;
-  int32_t points_per_block;
+  int32_t blocks_per_pair;    // k_residual_reduce grid.x
+  int32_t points_per_block;   // k_residual_reduce points per workgroup
+  int32_t tiles_per_pair;     // k_corr_search grid.x (256-point tiles)
+  int32_t use_lds;            // 0: always probe the global table per lane (A/B and parity checks)
 };
 
 }  // namespace pcm

@@ -47,8 +47,8 @@ struct LaunchGeom {
   int blocks_per_pair;
   int points_per_block;
 };
-void launch_p2plane(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
-                    unsigned long long* d_stats);
+void launch_corr_search(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, unsigned long long* d_stats);
+void launch_residual(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_sel);
 void launch_lsq_step(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const LsqParams& lp, int blocks_per_pair, int npairs, int* d_active_slot);
 void launch_reduce_only(hipStream_t stream, const PairDesc* d_descs, int blocks_per_pair, int npairs, double* d_sums /* npairs x 32 */);
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations);

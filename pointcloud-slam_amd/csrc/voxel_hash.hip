@@ -146,10 +146,32 @@ done:
 #undef CK
 }
 
-// Re-order a scan along the voxel grid (body frame) so that neighbouring lanes /
-// workgroups of the residual kernel touch neighbouring voxels.  Speed only: the
+// Re-order a scan along a Morton (Z-order) curve of its body-frame voxel
+// coordinates so that the 256 points of a k_corr_search tile fall into a few
+// neighbouring voxels (their voxel box then fits the LDS grid).  Speed only: the
 // normal equations are a sum over points, so the order never changes a result
 // beyond floating-point summation order.
+__device__ inline uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ void k_morton_keys(const float4* __restrict__ pts, uint32_t n, float inv_res, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  // body-frame cell index, clamped to +-512 cells around the sensor (beyond that only locality is lost)
+  const float cx = fminf(fmaxf(roundf(p.x * inv_res), -512.f), 511.f), cy = fminf(fmaxf(roundf(p.y * inv_res), -512.f), 511.f),
+              cz = fminf(fmaxf(roundf(p.z * inv_res), -512.f), 511.f);
+  const uint32_t ux = (uint32_t)((int)(cx == cx ? cx : 0.f) + 512), uy = (uint32_t)((int)(cy == cy ? cy : 0.f) + 512), uz = (uint32_t)((int)(cz == cz ? cz : 0.f) + 512);
+  keys[i] = spread10(ux) | (spread10(uy) << 1) | (spread10(uz) << 2);
+  idx[i] = i;
+}
+
 __global__ void k_scatter_sorted(const float4* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[idx[i]];
@@ -157,9 +179,7 @@ __global__ void k_scatter_sorted(const float4* __restrict__ in, const uint32_t* 
 
 int sort_source_along_grid(hipStream_t stream, float4* d_pts, uint32_t n, float res, std::string* err) {
   if (n == 0) return PCM_OK;
-  uint64_t *keys = nullptr, *keys_s = nullptr;
-  uint32_t *idx = nullptr, *idx_s = nullptr;
-  int* d_flag = nullptr;
+  uint32_t *keys = nullptr, *keys_s = nullptr, *idx = nullptr, *idx_s = nullptr;
   float4* tmp_pts = nullptr;
   void* tmp = nullptr;
   size_t tmp_bytes = 0;
@@ -169,24 +189,20 @@ int sort_source_along_grid(hipStream_t stream, float4* d_pts, uint32_t n, float 
     hipError_t e_ = (x);                                                         \
     if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
   } while (0)
-  CK(hipMalloc(&keys, sizeof(uint64_t) * n));
-  CK(hipMalloc(&keys_s, sizeof(uint64_t) * n));
-  CK(hipMalloc(&idx, sizeof(uint32_t) * n));
-  CK(hipMalloc(&idx_s, sizeof(uint32_t) * n));
-  CK(hipMalloc(&d_flag, sizeof(int)));
+  CK(hipMalloc(&keys, sizeof(uint32_t) * n * 4));
+  keys_s = keys + n; idx = keys + 2 * (size_t)n; idx_s = keys + 3 * (size_t)n;
   CK(hipMalloc(&tmp_pts, sizeof(float4) * n));
-  CK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
-  k_voxel_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, res, (float)(1.0 / res), COORD_ROUND, keys, idx, d_flag);
+  k_morton_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, (float)(1.0 / res), keys, idx);
   CK(hipGetLastError());
-  CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
+  CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 30, stream));
   CK(hipMalloc(&tmp, tmp_bytes));
-  CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
+  CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 30, stream));
   k_scatter_sorted<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, n, tmp_pts);
   CK(hipGetLastError());
   CK(hipMemcpyAsync(d_pts, tmp_pts, sizeof(float4) * n, hipMemcpyDeviceToDevice, stream));
   CK(hipStreamSynchronize(stream));
 done:
-  hipFree(keys); hipFree(keys_s); hipFree(idx); hipFree(idx_s); hipFree(d_flag); hipFree(tmp_pts); hipFree(tmp);
+  hipFree(keys); hipFree(tmp_pts); hipFree(tmp);
   return rc;
 #undef CK
 }

@@ -82,10 +82,45 @@ def test_known_answer_corner(pcm, synth):
     assert r.converged and dt < 1e-5 and dr < 1e-5
 
 
+def test_lds_path_equals_global_path(pcm, pair10k):
+    """The per-tile LDS voxel grid / staged points and the per-lane global probing
+    must pick exactly the same neighbours: bit-identical planes."""
+    p = pair10k
+    n = len(p.scan)
+    a = _gpu(pcm, sort_source=0); a.set_input_target(p.submap); a.set_input_source(p.scan)
+    b = _gpu(pcm, sort_source=0, flags=1); b.set_input_target(p.submap); b.set_input_source(p.scan)
+    for T in (p.T_gt, p.guess.astype(np.float64)):
+        ra, rb = a.evaluate_cost(T), b.evaluate_cost(T)
+        pa, pb = a.get_planes(n), b.get_planes(n)
+        assert np.array_equal(np.isnan(pa[:, 0]), np.isnan(pb[:, 0]))
+        ok = ~np.isnan(pa[:, 0])
+        assert np.array_equal(pa[ok], pb[ok])
+        assert ra[3] == rb[3] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+    # sorted scan: most tiles take the LDS path
+    c = _gpu(pcm, sort_source=1); c.set_input_target(p.submap); c.set_input_source(p.scan)
+    c.set_profiling(2); c.align(p.guess); st = c.stats()
+    assert st["tiles"] > 0 and st["tiles_lds_grid"] > 0
+
+
+def test_per_point_planes_match_oracle(pcm, pair10k):
+    """Per-point parity: same selected set, bit-identical fitted planes."""
+    p = pair10k
+    n = len(p.scan)
+    o = _oracle(); o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g = _gpu(pcm, sort_source=0); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    for T in (p.guess.astype(np.float64), p.T_gt):
+        o.linearize(T); g.evaluate_cost(T)
+        po, so = o.get_planes(n)
+        pg = g.get_planes(n)
+        sg = ~np.isnan(pg[:, 0])
+        assert np.array_equal(so, sg)
+        assert np.array_equal(po[so], pg[sg])
+
+
 def test_sorted_source_same_pose(pcm, pair10k):
     """sort_source only permutes the scan: same normal equations up to summation order."""
     p = pair10k
-    a = _gpu(pcm); a.set_input_target(p.submap); a.set_input_source(p.scan)
+    a = _gpu(pcm, sort_source=0); a.set_input_target(p.submap); a.set_input_source(p.scan)
     b = _gpu(pcm, sort_source=1); b.set_input_target(p.submap); b.set_input_source(p.scan)
     c0, H0, b0, i0 = a.evaluate_cost(p.T_gt)
     c1, H1, b1, i1 = b.evaluate_cost(p.T_gt)
