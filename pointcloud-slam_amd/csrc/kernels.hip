@@ -119,7 +119,7 @@ __device__ inline void probe_finish(const TargetView& tg, uint64_t key, uint32_t
     if (sk == key) { start = s.z; count = s.w; return; }
     if (sk == kEmptyKey) return;
     h = (h + 1) & tg.mask;
-    s = *reinterpret_cast<const uint4*>(&tg.slots[h]);
+    s = gload4u(&tg.slots[h]);
   }
 }
 
@@ -142,7 +142,7 @@ __device__ inline void knn_global(const TargetView& tg, const float (&q)[3], int
       const uint32_t hsum = hbase + (uint32_t)ox * 0x9E3779B1u + (uint32_t)oy * 0x85EBCA77u + (uint32_t)oz * 0xC2B2AE3Du;
       key[j] = (uint64_t)(kbase + ((int64_t)ox << 42) + ((int64_t)oy << 21) + (int64_t)oz);
       h[j] = hash_finish(hsum) & tg.mask;
-      s[j] = *reinterpret_cast<const uint4*>(&tg.slots[h[j]]);
+      s[j] = gload4u(&tg.slots[h[j]]);
     }
 #pragma unroll
     for (int j = 0; j < 9; j++) {
@@ -150,7 +150,7 @@ __device__ inline void knn_global(const TargetView& tg, const float (&q)[3], int
         uint32_t start, count;
         probe_finish<STATS>(tg, key[j], h[j], s[j], start, count, n_probe);
         for (uint32_t k = start; k < start + count; k++) {
-          const float4 mp = tg.pts[k];
+          const float4 mp = gload4(tg.pts + k);
           if (STATS) n_cand++;
           best_offer(best, mp, q, k, max_range_sq);
         }
@@ -165,7 +165,16 @@ __device__ inline void knn_global(const TargetView& tg, const float (&q)[3], int
 constexpr int kCapCells = 2048;   // LDS voxel grid of a tile (one packed word per cell)
 constexpr int kCapPts = 1024;     // map points staged per tile (float4 each)
 
-template <bool STATS>
+// TIMING (diagnostic build only): wave 0 / lane 0 of every tile stamps s_memtime at the
+// phase boundaries and adds the differences to stats[8..15]; nothing is computed from them.
+#define PCM_STAMP(slot)                                                        \
+  if (TIMING) {                                                                \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();             \
+    if (threadIdx.x == 0) atomicAdd(&stats[8 + (slot)], t_now - t_prev);       \
+    t_prev = t_now;                                                            \
+  }
+
+template <bool STATS, bool TIMING>
 __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
                                                      unsigned long long* __restrict__ stats) {
   const int pair = blockIdx.y;
@@ -187,12 +196,14 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
   __shared__ uint32_t s_jobid[256][4];     // the 3 or 4 neighbour ids of the job
 
   uint32_t n_cand = 0, n_probe = 0;
+  unsigned long long t_prev = 0;
+  if (TIMING) t_prev = __builtin_amdgcn_s_memtime();
   float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
   float q[3] = {0.f, 0.f, 0.f};
   int cx = 0, cy = 0, cz = 0;
   bool search = false;  // lanes whose query voxel lies inside the key range of the table
   if (live) {
-    p = d.src.pts[i];
+    p = gload4(d.src.pts + i);
     transform(P, p, q);
     const float fx = roundf(q[0] * tg.inv_res), fy = roundf(q[1] * tg.inv_res), fz = roundf(q[2] * tg.inv_res);  // Pos2Grid  ivox3d.h:283-286
     const float lim = (float)(kCoordBias - 4);
@@ -240,6 +251,7 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
   }
   __syncthreads();
   bool use_lds = s_box[7] != 0;   // uniform over the workgroup
+  PCM_STAMP(0)   // load + transform + tile box
 
   Best best;
   best_init(best);
@@ -265,7 +277,7 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
           const int vx = ox0 + x, vy = oy0 + y, vz = oz0 + z;
           key[j] = pack_key(vx, vy, vz);
           h[j] = hash_coord(vx, vy, vz) & tg.mask;
-          s[j] = *reinterpret_cast<const uint4*>(&tg.slots[h[j]]);
+          s[j] = gload4u(&tg.slots[h[j]]);
         }
       }
 #pragma unroll
@@ -279,6 +291,7 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
         }
       }
     }
+    PCM_STAMP(1)   // one global probe per cell
     // ---- exclusive scan of the per-cell point counts -> LDS offsets ---------------------------
     uint32_t incl = mysum;
 #pragma unroll
@@ -292,17 +305,33 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
     for (int w = 0; w < wave; w++) base += s_scan[w];
     const uint32_t total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
     use_lds = total <= (uint32_t)kCapPts;   // still uniform
+    PCM_STAMP(2)   // scan
     if (use_lds) {
       // ---- publish the cell grid; stage the box's map points through LDS ------------------------
-      uint32_t off = base;
+      uint32_t coff[8];
+      uint32_t off = base, maxc = 0;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int cell = threadIdx.x * 8 + j;
+        coff[j] = off;
         if (cell < ncell) s_cell[cell] = (off << 16) | ccount[j];
-        for (uint32_t k = 0; k < ccount[j]; k++) s_pts[off + k] = tg.pts[cstart[j] + k];
         off += ccount[j];
+        maxc = ccount[j] > maxc ? ccount[j] : maxc;
+      }
+      // round r copies the r-th point of each of this thread's 8 cells: 8 independent 16-byte loads in flight
+      for (uint32_t r = 0; r < maxc; r++) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (r < ccount[j]) v[j] = gload4(tg.pts + cstart[j] + r);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (r < ccount[j]) s_pts[coff[j] + r] = v[j];
+        }
       }
       __syncthreads();
+      PCM_STAMP(3)   // stage map points through LDS
       // ---- per-lane 27-cell / 5-NN search out of LDS (reference cell order) ----------------------
       if (search) {
         const int rx = cx - ox0, ry = cy - oy0, rz = cz - oz0;
@@ -319,6 +348,7 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
     }
   }
   if (!use_lds && search) knn_global<STATS>(tg, q, cx, cy, cz, kp.num_neighbors, kp.max_range_sq, best, n_cand, n_probe);
+  PCM_STAMP(4)   // 27-cell / 5-NN search
 
   // ---- plane fit on the <= 5 neighbours  (laser_mapping.cc:619-623) -----------------------------
   // 5 neighbours (the float path, almost every lane) is solved in place; the rare
@@ -331,7 +361,7 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
       float px[K], py[K], pz[K];
 #pragma unroll
       for (int j = 0; j < K; j++) {
-        const float4 mp = use_lds ? s_pts[best.i[j]] : tg.pts[best.i[j]];
+        const float4 mp = use_lds ? s_pts[best.i[j]] : gload4(tg.pts + best.i[j]);
         px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
       }
       float4 fit;
@@ -342,8 +372,9 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
 #pragma unroll
       for (int j = 0; j < 4; j++) s_jobid[job][j] = best.i[j];
     }
-    d.planes[i] = pl;
+    gstore4(d.planes + i, pl);
   }
+  PCM_STAMP(5)   // float plane fit
   __syncthreads();
   for (uint32_t job = threadIdx.x; job < s_njobs; job += 256) {
     const uint32_t owner = s_job[job] & 0xffffu, m = s_job[job] >> 16;
@@ -351,12 +382,14 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
 #pragma unroll
     for (int j = 0; j < K; j++) {
       float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < (int)m) mp = use_lds ? s_pts[s_jobid[job][j]] : tg.pts[s_jobid[job][j]];
+      if (j < (int)m) mp = use_lds ? s_pts[s_jobid[job][j]] : gload4(tg.pts + s_jobid[job][j]);
       px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
     }
     float4 fit;
-    if (esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) d.planes[blockIdx.x * 256u + owner] = fit;
+    if (esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) gstore4(d.planes + blockIdx.x * 256u + owner, fit);
   }
+  PCM_STAMP(6)   // queued double-precision fits
+  if (TIMING && threadIdx.x == 0) atomicAdd(&stats[15], 1ull);
   if (STATS) {
     unsigned long long c = n_cand, pr = n_probe;
 #pragma unroll
@@ -369,10 +402,12 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
   }
 }
 
-void launch_corr_search(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, unsigned long long* d_stats) {
+void launch_corr_search(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, unsigned long long* d_stats,
+                        bool timing) {
   dim3 grid((unsigned)kp.tiles_per_pair, (unsigned)npairs);
-  if (d_stats) k_corr_search<true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
-  else k_corr_search<false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
+  if (d_stats && timing) k_corr_search<false, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
+  else if (d_stats) k_corr_search<true, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
+  else k_corr_search<false, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
 }
 
 // ---------------------------------------------------------------------------
@@ -404,9 +439,9 @@ __global__ void __launch_bounds__(256) k_residual_reduce(const PairDesc* __restr
   end = end < d.src.num_points ? end : d.src.num_points;
 
   for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
-    const float4 pl = d.planes[i];
+    const float4 pl = gload4(d.planes + i);
     if (pl.x != pl.x) continue;  // no plane / not selected
-    const float4 p = d.src.pts[i];
+    const float4 p = gload4(d.src.pts + i);
     float q[3];
     transform(P, p, q);
     const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
@@ -415,7 +450,7 @@ __global__ void __launch_bounds__(256) k_residual_reduce(const PairDesc* __restr
       const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
       const bool sel = pn > 81.f * pd2 * pd2;                          // :631
       if (!sel) {
-        if (WRITE_SEL) d.planes[i].x = __builtin_nanf("");            // dropped for the following trial passes too
+        if (WRITE_SEL) gstore_f(&d.planes[i].x, __builtin_nanf(""));            // dropped for the following trial passes too
         continue;
       }
       // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
@@ -447,7 +482,7 @@ __global__ void __launch_bounds__(256) k_residual_reduce(const PairDesc* __restr
   __syncthreads();
   if (threadIdx.x < kNumSums) {
     const double v = ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
-    d.partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = v;
+    gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
   }
 }
 
@@ -465,7 +500,7 @@ __device__ inline void sum_partials(const double* __restrict__ partials, int blo
   const int j = threadIdx.x & 31, r = threadIdx.x >> 5;  // 8 row groups x 32 columns
   double v = 0.0;
   if (j < kNumSums) {
-    for (int b = r; b < blocks_per_pair; b += 8) v += partials[(size_t)b * kPartialStride + j];
+    for (int b = r; b < blocks_per_pair; b += 8) v += gload_d(partials + (size_t)b * kPartialStride + j);
   }
   s_sum[r * kPartialStride + j] = v;
   __syncthreads();

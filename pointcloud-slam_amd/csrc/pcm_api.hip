@@ -41,6 +41,8 @@ struct Workspace {
   int* d_active = nullptr;
   int* h_active = nullptr;  // pinned
   unsigned long long* d_stats = nullptr;
+  SortJob* d_jobs = nullptr;
+  SortScratch sort;
   int cap_pairs = 0;
   size_t cap_partials = 0;
   int cap_rounds = 0;
@@ -56,13 +58,14 @@ int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, i
   Workspace& w = g_ws[c->device];
   w.device = c->device;
   if (npairs > w.cap_pairs) {
-    if (w.d_descs) { hipFree(w.d_descs); hipFree(w.d_states); hipFree(w.d_guesses); hipFree(w.d_results); hipFree(w.d_sums); }
+    if (w.d_descs) { hipFree(w.d_descs); hipFree(w.d_states); hipFree(w.d_guesses); hipFree(w.d_results); hipFree(w.d_sums); hipFree(w.d_jobs); }
     const int cap = std::max(npairs, 64);
     HIPCK(c, hipMalloc(&w.d_descs, sizeof(PairDesc) * cap));
     HIPCK(c, hipMalloc(&w.d_states, sizeof(PairState) * cap));
     HIPCK(c, hipMalloc(&w.d_guesses, sizeof(float) * 16 * cap));
     HIPCK(c, hipMalloc(&w.d_results, sizeof(pcm_result) * cap));
     HIPCK(c, hipMalloc(&w.d_sums, sizeof(double) * kPartialStride * cap));
+    HIPCK(c, hipMalloc(&w.d_jobs, sizeof(SortJob) * cap));
     w.cap_pairs = cap;
   }
   if (partial_doubles > w.cap_partials) {
@@ -76,7 +79,7 @@ int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, i
     HIPCK(c, hipHostMalloc(&w.h_active, sizeof(int) * rounds));
     w.cap_rounds = rounds;
   }
-  if (!w.d_stats) HIPCK(c, hipMalloc(&w.d_stats, sizeof(unsigned long long) * 4));
+  if (!w.d_stats) HIPCK(c, hipMalloc(&w.d_stats, sizeof(unsigned long long) * 16));
   while ((int)w.ev_round.size() < 2) {
     hipEvent_t e;
     HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -130,10 +133,11 @@ int prepare(pcm_ctx* c) {
     c->stats.target_voxels = c->map.num_voxels;
     c->stats.target_slots = c->map.cap;
   }
-  if (c->cfg.sort_source && !c->src_sorted) {
-    int rc = sort_source_along_grid(c->stream, c->src.d_pts, (uint32_t)c->src.n, c->cfg.voxel_resolution, &c->err);
-    if (rc != PCM_OK) return rc;
-    c->src_sorted = true;
+  if (c->cfg.sort_source && c->src_order_cap < c->src.n) {
+    if (c->src_order) hipFree(c->src_order);
+    c->src_order = nullptr; c->src_order_cap = 0; c->src_sorted = false;
+    HIPCK(c, hipMalloc(&c->src_order, sizeof(float4) * c->src.n));
+    c->src_order_cap = c->src.n;
   }
   if (c->planes_cap < c->src.n) {
     if (c->planes) hipFree(c->planes);
@@ -170,7 +174,7 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->tgt.num_points = c->map.num_points;
   d->tgt.inv_res = c->map.inv_res;
   d->tgt.res = c->map.res;
-  d->src.pts = c->src.d_pts;
+  d->src.pts = (c->cfg.sort_source && c->src_sorted) ? c->src_order : c->src.d_pts;
   d->src.num_points = (uint32_t)c->src.n;
   d->planes = c->planes;
   d->partials = partials;
@@ -242,15 +246,34 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   if (rc != PCM_OK) return rc;
   hipStream_t st = c0->stream;
 
+  HIPCK(c0, hipMemcpyAsync(w->d_guesses, guesses, sizeof(float) * 16 * n, hipMemcpyHostToDevice, st));
+  {  // new scans are re-ordered along the world grid (at their initial guess) in one batched pass
+    std::vector<SortJob> jobs;
+    uint32_t total = 0, jmax = 0;
+    for (int i = 0; i < n; i++) {
+      pcm_ctx* c = ctxs[i];
+      if (!c->cfg.sort_source || c->src_sorted) continue;
+      SortJob j{c->src.d_pts, c->src_order, (uint32_t)c->src.n, total, (uint32_t)i, 0};
+      jobs.push_back(j);
+      total += j.n;
+      jmax = std::max(jmax, j.n);
+    }
+    if (!jobs.empty()) {
+      HIPCK(c0, hipMemcpyAsync(w->d_jobs, jobs.data(), sizeof(SortJob) * jobs.size(), hipMemcpyHostToDevice, st));
+      rc = sort_sources_batched(st, w->d_jobs, (int)jobs.size(), jmax, total, w->d_guesses, g.voxel_resolution, &w->sort, &c0->err);
+      if (rc != PCM_OK) return rc;
+      for (int i = 0; i < n; i++) if (ctxs[i]->cfg.sort_source) ctxs[i]->src_sorted = true;
+    }
+  }
   std::vector<PairDesc> descs(n);
   for (int i = 0; i < n; i++) fill_desc(ctxs[i], &descs[i], w->d_partials + per_pair_partials * i);
   HIPCK(c0, hipMemcpyAsync(w->d_descs, descs.data(), sizeof(PairDesc) * n, hipMemcpyHostToDevice, st));
-  HIPCK(c0, hipMemcpyAsync(w->d_guesses, guesses, sizeof(float) * 16 * n, hipMemcpyHostToDevice, st));
   HIPCK(c0, hipMemsetAsync(w->d_active, 0, sizeof(int) * max_rounds, st));
   launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations);
   const bool stats_on = (c0->profiling & 1) != 0;      // HIP events around the residual launches
-  const bool counters_on = (c0->profiling & 2) != 0;   // kNN candidate / probe counters (slower kernel variant)
-  if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 4, st));
+  const bool timing_on = (c0->profiling & 4) != 0;     // diagnostic: in-kernel phase stamps (stats.phase_cycles)
+  const bool counters_on = (c0->profiling & 2) != 0 || timing_on;   // kNN candidate / probe counters (slower kernel variant)
+  if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 16, st));
   const bool write_sel = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;  // trial passes re-use the selected set
 
   int rounds_done = 0;
@@ -260,7 +283,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       while (w->ev_prof.size() < prof_used + 3) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
       HIPCK(c0, hipEventRecord(w->ev_prof[prof_used], st));
     }
-    launch_corr_search(st, w->d_descs, w->d_states, kp, n, counters_on ? w->d_stats : nullptr);
+    launch_corr_search(st, w->d_descs, w->d_states, kp, n, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
     launch_residual(st, w->d_descs, w->d_states, kp, n, write_sel);
     if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st)); prof_used += 3; }
@@ -283,8 +306,9 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   HIPCK(c0, hipStreamSynchronize(st));
 
   if (counters_on) {
-    unsigned long long hs[4];
+    unsigned long long hs[16];
     HIPCK(c0, hipMemcpy(hs, w->d_stats, sizeof(hs), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; k++) c0->phase_cycles[k] += hs[8 + k];
     c0->stats.candidates += hs[0];
     c0->stats.slots_probed += hs[1];
     c0->stats.tiles += hs[3];
@@ -397,6 +421,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     c->src.release();
     c->tgt.release();
+    if (c->src_order) hipFree(c->src_order);
     c->map.release();
     if (c->planes) hipFree(c->planes);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -453,6 +478,7 @@ int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
 
 int pcm_swap_source_and_target(pcm_ctx* c) {
   CHECK_CTX(c);
+  HIPCK(c, hipStreamSynchronize(c->stream));
   std::swap(c->src, c->tgt);
   c->map.valid = false;
   c->src_sorted = false;
@@ -525,6 +551,12 @@ int pcm_get_planes(pcm_ctx* c, float* out, size_t n) {
   CHECK_CTX(c);
   if (!out || n != c->src.n || !c->planes) { c->err = "pcm_get_planes: call pcm_linearize first; n must equal the source size"; return PCM_ERR_INVALID_ARGUMENT; }
   HIPCK(c, hipMemcpy(out, c->planes, sizeof(float4) * n, hipMemcpyDeviceToHost));
+  return PCM_OK;
+}
+
+int pcm_debug_phase_cycles(pcm_ctx* c, uint64_t out[8]) {
+  if (!c || !out) return PCM_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < 8; k++) { out[k] = c->phase_cycles[k]; c->phase_cycles[k] = 0; }
   return PCM_OK;
 }
 

@@ -52,6 +52,28 @@ enum CoordMode : int32_t {
   COORD_FLOOR_HALF = 1   // fast_gicp: floor(p / res - 0.5)            include/fast_gicp/cuda/vector3_hash.cuh:35-38
 };
 
+// Explicit global-address-space accessors.  Pointers that reach a kernel through a
+// descriptor struct are generic to the compiler; a generic (flat) load counts on
+// both vmcnt and lgkmcnt and may alias LDS, which serialises every LDS write
+// behind it.  Going through address_space(1) gives global_load/global_store.
+#define PCM_GLOBAL __attribute__((address_space(1)))
+typedef float pcm_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int pcm_v4u __attribute__((ext_vector_type(4)));
+#if defined(__HIPCC__)
+__device__ inline float4 gload4(const float4* p) {
+  const pcm_v4f v = *(const PCM_GLOBAL pcm_v4f*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline uint4 gload4u(const void* p) {
+  const pcm_v4u v = *(const PCM_GLOBAL pcm_v4u*)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline void gstore4(float4* p, const float4& v) { *(PCM_GLOBAL pcm_v4f*)p = (pcm_v4f){v.x, v.y, v.z, v.w}; }
+__device__ inline void gstore_f(float* p, float v) { *(PCM_GLOBAL float*)p = v; }
+__device__ inline void gstore_d(double* p, double v) { *(PCM_GLOBAL double*)p = v; }
+__device__ inline double gload_d(const double* p) { return *(const PCM_GLOBAL double*)p; }
+#endif
+
 struct TargetView {
   const float4* pts;
   const Slot* slots;

@@ -39,7 +39,23 @@ struct TargetMap {
 
 int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, TargetMap* map, std::string* err);
 int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, float4* d_out, std::string* err);
-int sort_source_along_grid(hipStream_t stream, float4* d_pts, uint32_t n, float res, std::string* err);
+// batched scan re-ordering (voxel_hash.hip)
+struct SortJob {
+  const float4* src;   // scan in input order
+  float4* dst;         // scan along the world-grid Morton curve
+  uint32_t n;
+  uint32_t offset;     // first element of this scan in the concatenated key array
+  uint32_t guess_index;
+  uint32_t pad;
+};
+struct SortScratch {
+  uint64_t* keys = nullptr;   // 2 x cap
+  uint32_t* vals = nullptr;   // 2 x cap
+  void* tmp = nullptr;
+  size_t cap = 0, tmp_bytes = 0;
+};
+int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
+                         SortScratch* ws, std::string* err);
 
 // residual-kernel launchers (p2plane.hip)
 struct LaunchGeom {
@@ -47,7 +63,8 @@ struct LaunchGeom {
   int blocks_per_pair;
   int points_per_block;
 };
-void launch_corr_search(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, unsigned long long* d_stats);
+void launch_corr_search(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, unsigned long long* d_stats,
+                        bool timing = false);
 void launch_residual(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_sel);
 void launch_lsq_step(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const LsqParams& lp, int blocks_per_pair, int npairs, int* d_active_slot);
 void launch_reduce_only(hipStream_t stream, const PairDesc* d_descs, int blocks_per_pair, int npairs, double* d_sums /* npairs x 32 */);
@@ -63,10 +80,13 @@ struct pcm_ctx {
   bool own_stream = false;
   pcm::Cloud src, tgt;
   pcm::TargetMap map;
-  bool src_sorted = false;
+  float4* src_order = nullptr;   // the scan re-ordered along the world-grid Morton curve (speed only)
+  size_t src_order_cap = 0;
+  bool src_sorted = false;       // src_order holds the current source
   float4* planes = nullptr;
   size_t planes_cap = 0;
   std::string err;
   pcm_stats stats{};
+  uint64_t phase_cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic (profiling bit2)
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };

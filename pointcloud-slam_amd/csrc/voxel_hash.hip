@@ -146,11 +146,13 @@ done:
 #undef CK
 }
 
-// Re-order a scan along a Morton (Z-order) curve of its body-frame voxel
-// coordinates so that the 256 points of a k_corr_search tile fall into a few
-// neighbouring voxels (their voxel box then fits the LDS grid).  Speed only: the
-// normal equations are a sum over points, so the order never changes a result
-// beyond floating-point summation order.
+// Re-order the scans of a whole batch along a Morton (Z-order) curve of their WORLD
+// voxel coordinates at the initial guess, so that the 256 points of a
+// k_corr_search tile fall into a few neighbouring voxels of the submap grid
+// (their voxel box then fits the LDS grid).  One key kernel + one radix sort +
+// one gather for all pairs of the batch.  Speed only: the normal equations are a
+// sum over points, so the order never changes a result beyond floating-point
+// summation order.
 __device__ inline uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
   v &= 0x3ffu;
   v = (v | (v << 16)) & 0x030000ffu;
@@ -160,49 +162,72 @@ __device__ inline uint32_t spread10(uint32_t v) {  // 10 bits -> every third bit
   return v;
 }
 
-__global__ void k_morton_keys(const float4* __restrict__ pts, uint32_t n, float inv_res, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+// grid = (ceil(max_n / 256), npairs)
+__global__ void k_batch_morton_keys(const SortJob* __restrict__ jobs, const float* __restrict__ guesses, float inv_res, uint64_t* __restrict__ keys,
+                                    uint32_t* __restrict__ vals) {
+  const SortJob job = jobs[blockIdx.y];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  // body-frame cell index, clamped to +-512 cells around the sensor (beyond that only locality is lost)
-  const float cx = fminf(fmaxf(roundf(p.x * inv_res), -512.f), 511.f), cy = fminf(fmaxf(roundf(p.y * inv_res), -512.f), 511.f),
-              cz = fminf(fmaxf(roundf(p.z * inv_res), -512.f), 511.f);
-  const uint32_t ux = (uint32_t)((int)(cx == cx ? cx : 0.f) + 512), uy = (uint32_t)((int)(cy == cy ? cy : 0.f) + 512), uz = (uint32_t)((int)(cz == cz ? cz : 0.f) + 512);
-  keys[i] = spread10(ux) | (spread10(uy) << 1) | (spread10(uz) << 2);
-  idx[i] = i;
+  if (i >= job.n) return;
+  const float* T = guesses + 16 * job.guess_index;
+  const float4 p = gload4(job.src + i);
+  float c[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float q = (T[a * 4 + 0] * p.x + T[a * 4 + 1] * p.y) + T[a * 4 + 2] * p.z + T[a * 4 + 3];
+    // cell index relative to the sensor's cell, clamped to +-512 cells (beyond that only locality is lost)
+    const float r = roundf(q * inv_res) - roundf(T[a * 4 + 3] * inv_res);
+    c[a] = r == r ? fminf(fmaxf(r, -512.f), 511.f) : 0.f;
+  }
+  const uint32_t m = spread10((uint32_t)((int)c[0] + 512)) | (spread10((uint32_t)((int)c[1] + 512)) << 1) | (spread10((uint32_t)((int)c[2] + 512)) << 2);
+  keys[job.offset + i] = ((uint64_t)blockIdx.y << 32) | m;
+  vals[job.offset + i] = job.offset + i;
 }
 
-__global__ void k_scatter_sorted(const float4* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, float4* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[idx[i]];
+// grid = ceil(total / 256)
+__global__ void k_batch_gather(const SortJob* __restrict__ jobs, const uint64_t* __restrict__ keys_sorted, const uint32_t* __restrict__ vals_sorted, uint32_t total) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const SortJob job = jobs[(uint32_t)(keys_sorted[g] >> 32)];
+  gstore4(job.dst + (g - job.offset), gload4(job.src + (vals_sorted[g] - job.offset)));
 }
 
-int sort_source_along_grid(hipStream_t stream, float4* d_pts, uint32_t n, float res, std::string* err) {
-  if (n == 0) return PCM_OK;
-  uint32_t *keys = nullptr, *keys_s = nullptr, *idx = nullptr, *idx_s = nullptr;
-  float4* tmp_pts = nullptr;
-  void* tmp = nullptr;
-  size_t tmp_bytes = 0;
+int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
+                         SortScratch* ws, std::string* err) {
+  if (total == 0 || njobs == 0) return PCM_OK;
   int rc = PCM_OK;
 #define CK(x)                                                                    \
   do {                                                                           \
     hipError_t e_ = (x);                                                         \
     if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
   } while (0)
-  CK(hipMalloc(&keys, sizeof(uint32_t) * n * 4));
-  keys_s = keys + n; idx = keys + 2 * (size_t)n; idx_s = keys + 3 * (size_t)n;
-  CK(hipMalloc(&tmp_pts, sizeof(float4) * n));
-  k_morton_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, (float)(1.0 / res), keys, idx);
-  CK(hipGetLastError());
-  CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 30, stream));
-  CK(hipMalloc(&tmp, tmp_bytes));
-  CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 30, stream));
-  k_scatter_sorted<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, n, tmp_pts);
-  CK(hipGetLastError());
-  CK(hipMemcpyAsync(d_pts, tmp_pts, sizeof(float4) * n, hipMemcpyDeviceToDevice, stream));
-  CK(hipStreamSynchronize(stream));
+  {
+    int pair_bits = 1;
+    while ((1 << pair_bits) < njobs) pair_bits++;
+    size_t need = 0;
+    if (total > ws->cap) {
+      hipFree(ws->keys); hipFree(ws->vals); hipFree(ws->tmp);
+      ws->keys = nullptr; ws->vals = nullptr; ws->tmp = nullptr; ws->cap = 0; ws->tmp_bytes = 0;
+      CK(hipMalloc(&ws->keys, sizeof(uint64_t) * 2 * (size_t)total));
+      CK(hipMalloc(&ws->vals, sizeof(uint32_t) * 2 * (size_t)total));
+      ws->cap = total;
+    }
+    uint64_t* keys_s = ws->keys + ws->cap;
+    uint32_t* vals_s = ws->vals + ws->cap;
+    CK(rocprim::radix_sort_pairs(nullptr, need, ws->keys, keys_s, ws->vals, vals_s, total, 0, 32 + pair_bits, stream));
+    if (need > ws->tmp_bytes) {
+      hipFree(ws->tmp);
+      ws->tmp = nullptr; ws->tmp_bytes = 0;
+      CK(hipMalloc(&ws->tmp, need));
+      ws->tmp_bytes = need;
+    }
+    k_batch_morton_keys<<<dim3(cdiv(max_n, 256), (unsigned)njobs), 256, 0, stream>>>(d_jobs, d_guesses, (float)(1.0 / res), ws->keys, ws->vals);
+    CK(hipGetLastError());
+    need = ws->tmp_bytes;
+    CK(rocprim::radix_sort_pairs(ws->tmp, need, ws->keys, keys_s, ws->vals, vals_s, total, 0, 32 + pair_bits, stream));
+    k_batch_gather<<<cdiv(total, 256), 256, 0, stream>>>(d_jobs, keys_s, vals_s, total);
+    CK(hipGetLastError());
+  }
 done:
-  hipFree(keys); hipFree(tmp_pts); hipFree(tmp);
   return rc;
 #undef CK
 }

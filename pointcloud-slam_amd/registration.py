@@ -159,6 +159,11 @@ class Registration:
         self._check(self._L.pcm_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in capi.PcmStats._fields_ if k != "reserved"}
 
+    def phase_cycles(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self._L.pcm_debug_phase_cycles(self._h, out))
+        return list(out)
+
     def reset_stats(self): self._check(self._L.pcm_reset_stats(self._h))
 
 

@@ -20,3 +20,9 @@ g = np.stack([p.guess for p in pairs])
 for s in range(a.steps):
     res = pcm.align_batch(regs, g)
 print([r.num_linearize for r in res])
+regs[0].set_profiling(4)
+res = pcm.align_batch(regs, g)
+pc = regs[0].phase_cycles()
+n = max(1, pc[7])
+names = ['load+box', 'probe', 'scan', 'stage', 'search', 'fit', 'jobs']
+print('tiles', pc[7]); print({k: round(v / n) for k, v in zip(names, pc[:7])}, 'ticks/tile')
