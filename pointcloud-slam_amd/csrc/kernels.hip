@@ -108,53 +108,46 @@ __device__ inline void best_offer(Best& b, const float4& mp, const float (&q)[3]
 
 __device__ inline uint64_t slot_key(const uint4& s) { return ((uint64_t)s.y << 32) | s.x; }
 
-// resolve one voxel key against the global table, first slot already loaded
+// find a brick in the linear-probed brick table: slot index (or ~0u) and its first voxel
 template <bool STATS>
-__device__ inline void probe_finish(const TargetView& tg, uint64_t key, uint32_t h, uint4 s, uint32_t& start, uint32_t& count, uint32_t& n_probe) {
-  start = 0;
-  count = 0;
+__device__ inline uint32_t brick_find(const TargetView& tg, int bx, int by, int bz, uint32_t& vox_base, uint32_t& n_probe) {
+  const uint64_t key = pack_brick(bx, by, bz);
+  uint32_t h = hash_coord(bx, by, bz) & tg.mask;
   for (;;) {
+    const uint4 s = gload4u(&tg.bricks[h]);
     if (STATS) n_probe++;
     const uint64_t sk = slot_key(s);
-    if (sk == key) { start = s.z; count = s.w; return; }
-    if (sk == kEmptyKey) return;
+    if (sk == key) { vox_base = s.z; return h; }
+    if (sk == kEmptyKey) { vox_base = 0; return ~0u; }
     h = (h + 1) & tg.mask;
-    s = gload4u(&tg.slots[h]);
   }
 }
 
-// Per-lane search straight against the global table (tiles whose voxel box does
-// not fit the LDS grid).  The first probes of 9 cells are issued together so a
-// lane pays ~3 dependent memory round trips for its 27 cells instead of 27.
+// Per-lane search straight against the global structures (tiles whose voxel box
+// does not fit the LDS grid): brick probe (re-used while consecutive cells stay in
+// one brick) -> occupancy bit -> rank -> vox_start -> the voxel's points.
 template <bool STATS>
 __device__ inline void knn_global(const TargetView& tg, const float (&q)[3], int cx, int cy, int cz, int num_neighbors, float max_range_sq, Best& best,
                                   uint32_t& n_cand, uint32_t& n_probe) {
-  const uint32_t hbase = hash_part_x(cx) + hash_part_y(cy) + hash_part_z(cz);
-  const int64_t kbase = (int64_t)pack_key(cx, cy, cz);
-  for (int g0 = 0; g0 < num_neighbors; g0 += 9) {
-    uint4 s[9];
-    uint32_t h[9];
-    uint64_t key[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-      const int g = g0 + j < 27 ? g0 + j : 26;
-      const int ox = c_nearby[g][0], oy = c_nearby[g][1], oz = c_nearby[g][2];
-      const uint32_t hsum = hbase + (uint32_t)ox * 0x9E3779B1u + (uint32_t)oy * 0x85EBCA77u + (uint32_t)oz * 0xC2B2AE3Du;
-      key[j] = (uint64_t)(kbase + ((int64_t)ox << 42) + ((int64_t)oy << 21) + (int64_t)oz);
-      h[j] = hash_finish(hsum) & tg.mask;
-      s[j] = gload4u(&tg.slots[h[j]]);
+  int cbx = 0x7fffffff, cby = 0, cbz = 0;
+  uint32_t slot = ~0u, vox_base = 0;
+  for (int g = 0; g < num_neighbors; g++) {
+    const int vx = cx + c_nearby[g][0], vy = cy + c_nearby[g][1], vz = cz + c_nearby[g][2];
+    const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
+    if (bx != cbx || by != cby || bz != cbz) {
+      slot = brick_find<STATS>(tg, bx, by, bz, vox_base, n_probe);
+      cbx = bx; cby = by; cbz = bz;
     }
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-      if (g0 + j < num_neighbors) {
-        uint32_t start, count;
-        probe_finish<STATS>(tg, key[j], h[j], s[j], start, count, n_probe);
-        for (uint32_t k = start; k < start + count; k++) {
-          const float4 mp = gload4(tg.pts + k);
-          if (STATS) n_cand++;
-          best_offer(best, mp, q, k, max_range_sq);
-        }
-      }
+    if (slot == ~0u) continue;
+    const uint32_t li = local_index(vx, vy, vz), w = li >> 5, bit = li & 31;
+    const uint32_t m = gload_u(&tg.bmask[(size_t)slot * 16 + w]);
+    if (!((m >> bit) & 1u)) continue;
+    const uint32_t v = vox_base + gload_u16(&tg.bpref[(size_t)slot * 16 + w]) + (uint32_t)__popc(m & ((1u << bit) - 1u));
+    const uint32_t start = gload_u(&tg.vox_start[v]), end = gload_u(&tg.vox_start[v + 1]);
+    for (uint32_t k = start; k < end; k++) {
+      const float4 mp = gload4(tg.pts + k);
+      if (STATS) n_cand++;
+      best_offer(best, mp, q, k, max_range_sq);
     }
   }
 }
@@ -162,11 +155,13 @@ __device__ inline void knn_global(const TargetView& tg, const float (&q)[3], int
 // ---------------------------------------------------------------------------
 // k_corr_search: grid = (tiles_per_pair, npairs), block = 256, one scan point per lane
 // ---------------------------------------------------------------------------
-constexpr int kCapCells = 2048;   // LDS voxel grid of a tile (one packed word per cell)
-constexpr int kCapPts = 1024;     // map points staged per tile (float4 each)
+constexpr int kCapCells = 2048;   // LDS voxel grid of a tile (one uint16 per cell)
+constexpr int kCapPts = 1792;     // map points staged per tile (float4 each); keeps the workgroup under 40 KB of LDS (4 per CU)
+constexpr int kCapBricks = 64;    // bricks under a tile box
+constexpr uint16_t kNoCell = 0xffffu;
 
-// TIMING (diagnostic build only): wave 0 / lane 0 of every tile stamps s_memtime at the
-// phase boundaries and adds the differences to stats[8..15]; nothing is computed from them.
+// TIMING (diagnostic build only): lane 0 of every tile stamps s_memtime at the phase
+// boundaries and adds the differences to stats[8..15]; nothing is computed from them.
 #define PCM_STAMP(slot)                                                        \
   if (TIMING) {                                                                \
     const unsigned long long t_now = __builtin_amdgcn_s_memtime();             \
@@ -187,11 +182,13 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
   const TargetView tg = d.tgt;
 
   __shared__ int s_red[4][6];
-  __shared__ int s_box[8];             // origin xyz, dims xyz, ncell, dense flag
-  __shared__ uint32_t s_scan[4];
+  __shared__ int s_box[8];                 // origin xyz, dims xyz, ncell, dense flag
+  __shared__ int s_bbox[8];                // first brick xyz, brick dims xyz, nbricks
+  __shared__ uint32_t s_bps[kCapBricks];   // first map point of each brick under the box
+  __shared__ uint32_t s_boff[kCapBricks + 1];  // its offset in s_pts (exclusive scan of the point counts)
   __shared__ uint32_t s_njobs;
-  __shared__ uint32_t s_cell[kCapCells];   // (offset into s_pts) << 16 | count
-  __shared__ float4 s_pts[kCapPts];
+  __shared__ uint16_t s_cell[kCapCells];   // first staged point of the voxel in that cell, kNoCell when empty
+  __shared__ float4 s_pts[kCapPts];        // the bricks' map points, .w = voxel tag
   __shared__ uint32_t s_job[256];          // owner tid | m << 16
   __shared__ uint32_t s_jobid[256][4];     // the 3 or 4 neighbour ids of the job
 
@@ -206,7 +203,7 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
     p = gload4(d.src.pts + i);
     transform(P, p, q);
     const float fx = roundf(q[0] * tg.inv_res), fy = roundf(q[1] * tg.inv_res), fz = roundf(q[2] * tg.inv_res);  // Pos2Grid  ivox3d.h:283-286
-    const float lim = (float)(kCoordBias - 4);
+    const float lim = (float)(kCoordBias - 32);
     search = fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim;  // also false for NaN
     if (search) { cx = (int)fx; cy = (int)fy; cz = (int)fz; }
   }
@@ -246,6 +243,17 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
       ncell = ok ? ncell * (int)dim : ncell;
       if (ncell > kCapCells) ok = false;
     }
+    if (ok) {  // bricks under the box
+      int nb = 1;
+      for (int a = 0; a < 3; a++) {
+        const int blo = s_box[a] >> kBrickShift, bhi = (s_box[a] + s_box[3 + a] - 1) >> kBrickShift;
+        s_bbox[a] = blo;
+        s_bbox[3 + a] = bhi - blo + 1;
+        nb *= bhi - blo + 1;
+      }
+      s_bbox[6] = nb;
+      if (nb > kCapBricks) ok = false;
+    }
     s_box[6] = ncell;
     s_box[7] = ok ? 1 : 0;
   }
@@ -258,90 +266,95 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
 
   if (use_lds) {
     const int ox0 = s_box[0], oy0 = s_box[1], oz0 = s_box[2];
-    const int Dy = s_box[4], Dz = s_box[5], ncell = s_box[6];
-    // ---- one global probe per cell of the box: thread t owns cells [8t, 8t+8) -----------------
-    uint32_t cstart[8], ccount[8];
-    uint32_t mysum = 0;
-    {
-      uint4 s[8];
-      uint32_t h[8];
-      uint64_t key[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int cell = threadIdx.x * 8 + j;
-        key[j] = 0;
-        h[j] = 0;
-        s[j] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
-        if (cell < ncell) {
-          const int z = cell % Dz, xy = cell / Dz, y = xy % Dy, x = xy / Dy;
-          const int vx = ox0 + x, vy = oy0 + y, vz = oz0 + z;
-          key[j] = pack_key(vx, vy, vz);
-          h[j] = hash_coord(vx, vy, vz) & tg.mask;
-          s[j] = gload4u(&tg.slots[h[j]]);
+    const int Dx = s_box[3], Dy = s_box[4], Dz = s_box[5], ncell = s_box[6];
+    const int bx0 = s_bbox[0], by0 = s_bbox[1], bz0 = s_bbox[2], nby = s_bbox[4], nbz = s_bbox[5], nb = s_bbox[6];
+    // ---- one probe per BRICK under the box (wave 0), exclusive scan of their point counts -------
+    if (wave == 0) {
+      uint32_t npts = 0, ps = 0;
+      if (lane < nb) {
+        const int z = lane % nbz, xy = lane / nbz, y = xy % nby, x = xy / nby;
+        const uint64_t key = pack_brick(bx0 + x, by0 + y, bz0 + z);
+        uint32_t h = hash_coord(bx0 + x, by0 + y, bz0 + z) & tg.mask;
+        for (;;) {
+          const uint4 s0 = gload4u(&tg.bricks[h]);
+          if (STATS) n_probe++;
+          const uint64_t sk = slot_key(s0);
+          if (sk == key) { const uint4 s1 = gload4u(reinterpret_cast<const char*>(&tg.bricks[h]) + 16); ps = s1.x; npts = s1.y; break; }
+          if (sk == kEmptyKey) break;
+          h = (h + 1) & tg.mask;
         }
       }
+      uint32_t incl = npts;
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int cell = threadIdx.x * 8 + j;
-        cstart[j] = 0;
-        ccount[j] = 0;
-        if (cell < ncell) {
-          probe_finish<STATS>(tg, key[j], h[j], s[j], cstart[j], ccount[j], n_probe);
-          mysum += ccount[j];
-        }
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
       }
+      if (lane < nb) { s_bps[lane] = ps; s_boff[lane] = incl - npts; }
+      if (lane == 63) s_boff[kCapBricks] = incl;   // total
     }
-    PCM_STAMP(1)   // one global probe per cell
-    // ---- exclusive scan of the per-cell point counts -> LDS offsets ---------------------------
-    uint32_t incl = mysum;
+    // meanwhile everybody clears the cell grid
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) s_scan[wave] = incl;
+    for (int j = 0; j < kCapCells / 256; j++) s_cell[threadIdx.x + 256 * j] = kNoCell;
     __syncthreads();
-    uint32_t base = incl - mysum;
-    for (int w = 0; w < wave; w++) base += s_scan[w];
-    const uint32_t total = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    const uint32_t total = s_boff[kCapBricks];
     use_lds = total <= (uint32_t)kCapPts;   // still uniform
-    PCM_STAMP(2)   // scan
+    PCM_STAMP(1)   // brick probes
     if (use_lds) {
-      // ---- publish the cell grid; stage the box's map points through LDS ------------------------
-      uint32_t coff[8];
-      uint32_t off = base, maxc = 0;
+      // ---- stage the bricks' map points through LDS: flat, coalesced, all loads in flight --------
+      float4 v[kCapPts / 256];
+      int vb[kCapPts / 256];
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int cell = threadIdx.x * 8 + j;
-        coff[j] = off;
-        if (cell < ncell) s_cell[cell] = (off << 16) | ccount[j];
-        off += ccount[j];
-        maxc = ccount[j] > maxc ? ccount[j] : maxc;
-      }
-      // round r copies the r-th point of each of this thread's 8 cells: 8 independent 16-byte loads in flight
-      for (uint32_t r = 0; r < maxc; r++) {
-        float4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          if (r < ccount[j]) v[j] = gload4(tg.pts + cstart[j] + r);
+      for (int r = 0; r < kCapPts / 256; r++) {
+        const uint32_t k = threadIdx.x + 256u * r;
+        vb[r] = -1;
+        if (k < total) {
+          int b = 0;
+          while (b + 1 < nb && s_boff[b + 1] <= k) b++;   // nb is small (typically 1..8)
+          vb[r] = b;
+          v[r] = gload4(tg.pts + s_bps[b] + (k - s_boff[b]));
         }
+      }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          if (r < ccount[j]) s_pts[coff[j] + r] = v[j];
+      for (int r = 0; r < kCapPts / 256; r++) {
+        const uint32_t k = threadIdx.x + 256u * r;
+        if (k < total) s_pts[k] = v[r];
+      }
+      __syncthreads();
+      PCM_STAMP(2)   // stage map points
+      // ---- every voxel head among the staged points registers itself in the cell grid ------------
+#pragma unroll
+      for (int r = 0; r < kCapPts / 256; r++) {
+        const uint32_t k = threadIdx.x + 256u * r;
+        if (k < total) {
+          const int tag = __float_as_int(v[r].w);
+          const bool head = k == s_boff[vb[r]] || __float_as_int(s_pts[k - 1].w) != tag;
+          if (head) {
+            const int b = vb[r], bz = b % nbz, bxy = b / nbz, by = bxy % nby, bx = bxy / nby;
+            const int li = tag & 511;
+            const int x = ((bx0 + bx) << kBrickShift) + (li >> 6) - ox0, y = ((by0 + by) << kBrickShift) + ((li >> 3) & 7) - oy0,
+                      z = ((bz0 + bz) << kBrickShift) + (li & 7) - oz0;
+            if (x >= 0 && x < Dx && y >= 0 && y < Dy && z >= 0 && z < Dz) s_cell[(x * Dy + y) * Dz + z] = (uint16_t)k;
+          }
         }
       }
       __syncthreads();
-      PCM_STAMP(3)   // stage map points through LDS
+      PCM_STAMP(3)   // cell grid
       // ---- per-lane 27-cell / 5-NN search out of LDS (reference cell order) ----------------------
       if (search) {
         const int rx = cx - ox0, ry = cy - oy0, rz = cz - oz0;
         for (int g = 0; g < kp.num_neighbors; g++) {
           const int cell = ((rx + c_nearby[g][0]) * Dy + (ry + c_nearby[g][1])) * Dz + (rz + c_nearby[g][2]);
-          const uint32_t c = s_cell[cell];
-          const uint32_t k0 = c >> 16, k1 = k0 + (c & 0xffffu);
-          for (uint32_t k = k0; k < k1; k++) {
+          uint32_t k = s_cell[cell];
+          if (k == kNoCell) continue;
+          float4 mp = s_pts[k];
+          const int tag = __float_as_int(mp.w);
+          for (;;) {   // the voxel's points: consecutive staged points with the same tag
             if (STATS) n_cand++;
-            best_offer(best, s_pts[k], q, k, kp.max_range_sq);
+            best_offer(best, mp, q, k, kp.max_range_sq);
+            if (++k >= total) break;
+            mp = s_pts[k];
+            if (__float_as_int(mp.w) != tag) break;
           }
         }
       }

@@ -169,7 +169,10 @@ Geom pick_geom(size_t max_n, int npairs) {
 
 void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->tgt.pts = c->map.pts;
-  d->tgt.slots = c->map.slots;
+  d->tgt.vox_start = c->map.vox_start;
+  d->tgt.bricks = c->map.bricks;
+  d->tgt.bmask = c->map.bmask;
+  d->tgt.bpref = c->map.bpref;
   d->tgt.mask = c->map.cap - 1;
   d->tgt.num_points = c->map.num_points;
   d->tgt.inv_res = c->map.inv_res;

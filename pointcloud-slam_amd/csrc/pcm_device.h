@@ -1,14 +1,22 @@
-// pcm_device.h -- device-side data layout shared by the build and residual kernels.
+// pcm_device.h -- device-side data layout shared by the build and search kernels.
 //
 // HBM layout of one target (submap), built once in pcm_set_target():
-//   pts      float4[M]   map points grouped by voxel (voxels in ascending key
-//                        order, points of a voxel in input order); .w carries
-//                        the original input index as raw int bits
-//   slots    Slot[cap]   linear-probed voxel hash, cap = pow2 >= 4 * #voxels
-//                        (load <= 0.25 so a miss ends after ~1.3 probes);
-//                        16-byte slot like the reference's CUDA bucket
-//                        (pair<Vector3i,int>, gaussian_voxelmap.cuh:33)
-// One source (scan): float4[N] (optionally re-ordered along the voxel grid).
+//   pts        float4[M]      map points grouped by voxel; voxels grouped by 8x8x8
+//                             BRICK (brick-major, then z-fastest inside the brick), so
+//                             all points of a brick are ONE contiguous run; .w carries
+//                             the voxel tag (brick slot << 9 | voxel-in-brick) as raw
+//                             int bits: equal tags <=> same voxel
+//   vox_start  uint32[V+1]    first point of every occupied voxel, same order
+//   bricks     BrickSlot[cap] linear-probed hash of the occupied bricks (cap = pow2 >=
+//                             4 x #bricks); the reference's CUDA bucket is one
+//                             pair<Vector3i,int> per VOXEL (gaussian_voxelmap.cuh:33)
+//   bmask      uint32[cap*16] 512-bit voxel occupancy of the brick in that slot
+//   bpref      uint16[cap*16] occupied voxels before each mask word (rank prefix)
+// A voxel lookup = one brick probe (shared by up to 512 cells), one mask bit, one
+// popcount and two adjacent vox_start words.  For a LiDAR surface map the whole index
+// (bricks + masks + vox_start) is a few MB per 1 M points and stays in L2 / Infinity
+// Cache; only the map points themselves stream from HBM.
+// One source (scan): float4[N] (re-ordered along the voxel grid for locality).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,25 +25,31 @@
 namespace pcm {
 
 constexpr int kCoordBias = 1 << 20;        // voxel coords must lie in [-2^20, 2^20)
+constexpr int kBrickShift = 3;             // 8 x 8 x 8 voxels per brick
+constexpr int kBrickBias = 1 << 17;        // brick coords lie in [-2^17, 2^17)
 constexpr uint64_t kEmptyKey = ~0ull;
 
-struct Slot {
-  uint64_t key;    // packed voxel coordinate, kEmptyKey when free
-  uint32_t start;  // first point of the voxel in `pts`
-  uint32_t count;  // number of points
+struct BrickSlot {
+  uint64_t key;       // packed brick coordinate, kEmptyKey when free
+  uint32_t vox_base;  // index of the brick's first occupied voxel in vox_start
+  uint32_t nvox;      // occupied voxels in the brick
+  uint32_t pt_start;  // first map point of the brick in pts
+  uint32_t npts;      // map points in the brick (contiguous)
+  uint32_t pad[2];
 };
-static_assert(sizeof(Slot) == 16, "Slot must be 16 bytes");
+static_assert(sizeof(BrickSlot) == 32, "BrickSlot must be 32 bytes");
+constexpr uint32_t kMaxBrickSlots = 1u << 22;  // slot index must fit the 22 tag bits of pts.w
 
-__host__ __device__ inline uint64_t pack_key(int x, int y, int z) {
-  return ((uint64_t)(uint32_t)(x + kCoordBias) << 42) | ((uint64_t)(uint32_t)(y + kCoordBias) << 21) |
-         (uint64_t)(uint32_t)(z + kCoordBias);
+__host__ __device__ inline uint64_t pack_brick(int bx, int by, int bz) {
+  return ((uint64_t)(uint32_t)(bx + kBrickBias) << 36) | ((uint64_t)(uint32_t)(by + kBrickBias) << 18) | (uint64_t)(uint32_t)(bz + kBrickBias);
+}
+// voxel index inside its brick, z fastest
+__host__ __device__ inline uint32_t local_index(int x, int y, int z) { return (uint32_t)(((x & 7) << 6) | ((y & 7) << 3) | (z & 7)); }
+// sort key of a point: brick-major, then local voxel index
+__host__ __device__ inline uint64_t point_key(int x, int y, int z) {
+  return (pack_brick(x >> kBrickShift, y >> kBrickShift, z >> kBrickShift) << 9) | local_index(x, y, z);
 }
 
-// 32-bit mix of the three coordinates; additive in each coordinate before the
-// finaliser so the 27 neighbour hashes share their partial products.
-__host__ __device__ inline uint32_t hash_part_x(int x) { return (uint32_t)x * 0x9E3779B1u; }
-__host__ __device__ inline uint32_t hash_part_y(int y) { return (uint32_t)y * 0x85EBCA77u; }
-__host__ __device__ inline uint32_t hash_part_z(int z) { return (uint32_t)z * 0xC2B2AE3Du; }
 __host__ __device__ inline uint32_t hash_finish(uint32_t h) {
   h ^= h >> 15;
   h *= 0x2C1B3C6Du;
@@ -43,7 +57,7 @@ __host__ __device__ inline uint32_t hash_finish(uint32_t h) {
   return h;
 }
 __host__ __device__ inline uint32_t hash_coord(int x, int y, int z) {
-  return hash_finish(hash_part_x(x) + hash_part_y(y) + hash_part_z(z));
+  return hash_finish((uint32_t)x * 0x9E3779B1u + (uint32_t)y * 0x85EBCA77u + (uint32_t)z * 0xC2B2AE3Du);
 }
 
 // voxel-coordinate conventions of the reference
@@ -68,6 +82,13 @@ __device__ inline uint4 gload4u(const void* p) {
   const pcm_v4u v = *(const PCM_GLOBAL pcm_v4u*)p;
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ inline uint2 gload2u(const void* p) {
+  typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+  const v2u v = *(const PCM_GLOBAL v2u*)p;
+  return make_uint2(v.x, v.y);
+}
+__device__ inline uint32_t gload_u(const uint32_t* p) { return *(const PCM_GLOBAL uint32_t*)p; }
+__device__ inline uint32_t gload_u16(const uint16_t* p) { return *(const PCM_GLOBAL uint16_t*)p; }
 __device__ inline void gstore4(float4* p, const float4& v) { *(PCM_GLOBAL pcm_v4f*)p = (pcm_v4f){v.x, v.y, v.z, v.w}; }
 __device__ inline void gstore_f(float* p, float v) { *(PCM_GLOBAL float*)p = v; }
 __device__ inline void gstore_d(double* p, double v) { *(PCM_GLOBAL double*)p = v; }
@@ -76,8 +97,11 @@ __device__ inline double gload_d(const double* p) { return *(const PCM_GLOBAL do
 
 struct TargetView {
   const float4* pts;
-  const Slot* slots;
-  uint32_t mask;       // cap - 1
+  const uint32_t* vox_start;
+  const BrickSlot* bricks;
+  const uint32_t* bmask;
+  const uint16_t* bpref;
+  uint32_t mask;       // brick-table capacity - 1
   uint32_t num_points;
   float inv_res;       // float(1.0 / res)
   float res;

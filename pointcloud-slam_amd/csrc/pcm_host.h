@@ -23,17 +23,24 @@ struct Cloud {
   }
 };
 
-struct TargetMap {
-  Slot* slots = nullptr;
-  float4* pts = nullptr;  // grouped by voxel
-  uint32_t cap = 0, num_voxels = 0, num_points = 0;
+struct TargetMap {   // layout: pcm_device.h
+  BrickSlot* bricks = nullptr;
+  uint32_t* bmask = nullptr;
+  uint16_t* bpref = nullptr;
+  uint32_t* vox_start = nullptr;
+  float4* pts = nullptr;
+  uint32_t cap = 0, num_voxels = 0, num_bricks = 0, num_points = 0;
   float res = 0.f, inv_res = 0.f;
   int coord_mode = 0;
   bool valid = false;
   void release() {
-    if (slots) hipFree(slots);
+    if (bricks) hipFree(bricks);
+    if (bmask) hipFree(bmask);
+    if (bpref) hipFree(bpref);
+    if (vox_start) hipFree(vox_start);
     if (pts) hipFree(pts);
-    slots = nullptr; pts = nullptr; cap = num_voxels = num_points = 0; valid = false;
+    bricks = nullptr; bmask = nullptr; bpref = nullptr; vox_start = nullptr; pts = nullptr;
+    cap = num_voxels = num_bricks = num_points = 0; valid = false;
   }
 };
 

@@ -1,20 +1,24 @@
-// voxel_hash.hip -- device-side build of the submap voxel hash (pcm_set_target).
+// voxel_hash.hip -- device-side build of the submap voxel hash (pcm_set_target) and
+// the batched re-ordering of new scans.
 //
 // Replaces, for the MI355X path:
 //   - IVox::AddPoints bulk insert        /root/reference/src/jueying_lio/include/ivox3d/ivox3d.h:256-281
 //   - GaussianVoxelMap::create_bucket_table (linear-probed buckets, atomicCAS insert)
 //                                        /root/reference/src/pointcloud_match/fast_gicp/src/fast_gicp/cuda/gaussian_voxelmap.cu:21-58,258-289
-// Design (not a port): the reference inserts every POINT with an atomicCAS and
-// doubles the table until <1 % of points fail; here the points are radix-sorted
-// by voxel key once (stable, so a voxel keeps its points in input order), each
-// VOXEL is inserted exactly once, the table is sized up front from the voxel
-// count (load <= 0.25, probing is unbounded, no insertion ever fails), and the
-// point array is re-ordered so a voxel's points are one contiguous HBM run.
+// Design (not a port): the reference inserts every POINT with an atomicCAS into a
+// table of one bucket per voxel and doubles the table until <1 % of points fail.
+// Here the points are radix-sorted once by (brick, voxel-in-brick) key (stable, so a
+// voxel keeps its points in input order), the hash holds one slot per 8x8x8 BRICK
+// with a 512-bit occupancy mask, the table is sized up front from the brick count
+// (load <= 0.25, unbounded probing, no insertion ever fails), and points and voxels
+// are laid out brick-major so everything under a search tile is a few contiguous
+// runs (layout: pcm_device.h).
 #include "pcm_device.h"
 #include "pcm_host.h"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace pcm {
 
@@ -31,7 +35,7 @@ __device__ inline int voxel_coord(float v, float res, float inv_res, int mode) {
   return (int)floorf(v / res - 0.5f);                         // vector3_hash.cuh:35-38
 }
 
-__global__ void k_voxel_keys(const float4* __restrict__ pts, uint32_t n, float res, float inv_res, int mode,
+__global__ void k_point_keys(const float4* __restrict__ pts, uint32_t n, float res, float inv_res, int mode,
                              uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, int* __restrict__ oor) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -39,62 +43,110 @@ __global__ void k_voxel_keys(const float4* __restrict__ pts, uint32_t n, float r
   int c[3] = {voxel_coord(p.x, res, inv_res, mode), voxel_coord(p.y, res, inv_res, mode), voxel_coord(p.z, res, inv_res, mode)};
   bool bad = !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z));
   for (int a = 0; a < 3; a++) {
-    // keep one cell of slack so that neighbour offsets (+-1) never leave the key range
-    if (c[a] < -kCoordBias + 2 || c[a] > kCoordBias - 3) { bad = true; c[a] = 0; }
+    // keep a few cells of slack so that neighbour offsets never leave the key range
+    if (c[a] < -kCoordBias + 16 || c[a] > kCoordBias - 17) { bad = true; c[a] = 0; }
   }
   if (bad) atomicOr(oor, 1);
-  keys[i] = pack_key(c[0], c[1], c[2]);
+  keys[i] = point_key(c[0], c[1], c[2]);
   idx[i] = i;
 }
 
-__global__ void k_count_heads(const uint64_t* __restrict__ keys, uint32_t n, unsigned int* __restrict__ count) {
+// voxel-head flags (input of the rank scan) + number of brick heads
+__global__ void k_head_flags(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ vflag, unsigned int* __restrict__ nbricks) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-  const unsigned long long m = __ballot(head);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned int)__popcll(m));
+  bool bhead = false;
+  if (i < n) {
+    const uint64_t k = keys[i];
+    const uint64_t kp = i ? keys[i - 1] : ~k;
+    vflag[i] = k != kp ? 1u : 0u;
+    bhead = (k >> 9) != (kp >> 9);
+  }
+  __shared__ unsigned int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const unsigned long long m = __ballot(bhead);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned int)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) atomicAdd(nbricks, s_cnt);
 }
 
-// one insertion per voxel: the head point of each run of equal keys claims a slot
-__global__ void k_insert_voxels(const uint64_t* __restrict__ keys, uint32_t n, Slot* __restrict__ slots, uint32_t mask) {
+// one insertion per brick: the first point of each brick claims a slot
+__global__ void k_insert_bricks(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vrank, uint32_t n, BrickSlot* __restrict__ slots, uint32_t mask) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint64_t key = keys[i];
-  if (i != 0 && keys[i - 1] == key) return;
-  uint32_t cnt = 1;
-  while (i + cnt < n && keys[i + cnt] == key) cnt++;
-  const int x = (int)(key >> 42) - kCoordBias, y = (int)((key >> 21) & 0x1fffff) - kCoordBias, z = (int)(key & 0x1fffff) - kCoordBias;
-  uint32_t h = hash_coord(x, y, z) & mask;
+  const uint64_t bkey = keys[i] >> 9;
+  if (i != 0 && (keys[i - 1] >> 9) == bkey) return;
+  const int bx = (int)(bkey >> 36) - kBrickBias, by = (int)((bkey >> 18) & 0x3ffff) - kBrickBias, bz = (int)(bkey & 0x3ffff) - kBrickBias;
+  uint32_t h = hash_coord(bx, by, bz) & mask;
   for (;;) {
-    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[h].key), (unsigned long long)kEmptyKey, (unsigned long long)key);
-    if (prev == kEmptyKey) {  // keys are unique per voxel, so a claimed slot is ours alone
-      slots[h].start = i;
-      slots[h].count = cnt;
+    const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&slots[h].key), (unsigned long long)kEmptyKey, (unsigned long long)bkey);
+    if (prev == kEmptyKey) {  // brick keys are unique, so a claimed slot is ours alone
+      slots[h].vox_base = vrank[i];
+      slots[h].nvox = 0;
+      slots[h].pt_start = 0;
+      slots[h].npts = 0;
       return;
     }
     h = (h + 1) & mask;
   }
 }
 
-__global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* __restrict__ idx, uint32_t n, float4* __restrict__ out) {
+// one pass per voxel: first point index, occupancy bit, voxel count of the brick
+__global__ void k_fill_voxels(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vrank, uint32_t n,
+                              uint32_t nvox_total, uint32_t* __restrict__ vox_start, BrickSlot* __restrict__ slots, uint32_t* __restrict__ bmask, uint32_t mask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) vox_start[nvox_total] = n;
+  if (i >= n || !vflag[i]) return;
+  vox_start[vrank[i]] = i;
+  const uint64_t bkey = keys[i] >> 9;
+  const uint32_t li = (uint32_t)(keys[i] & 511u);
+  const int bx = (int)(bkey >> 36) - kBrickBias, by = (int)((bkey >> 18) & 0x3ffff) - kBrickBias, bz = (int)(bkey & 0x3ffff) - kBrickBias;
+  uint32_t h = hash_coord(bx, by, bz) & mask;
+  while (slots[h].key != bkey) h = (h + 1) & mask;  // inserted by the previous kernel
+  atomicOr(&bmask[(size_t)h * 16 + (li >> 5)], 1u << (li & 31));
+  atomicAdd(&slots[h].nvox, 1u);
+}
+
+// rank prefix of every mask word; point range of the brick
+__global__ void k_finalize_bricks(BrickSlot* __restrict__ slots, const uint32_t* __restrict__ bmask, uint16_t* __restrict__ bpref, const uint32_t* __restrict__ vox_start,
+                                  uint32_t cap) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= cap || slots[h].key == kEmptyKey) return;
+  const uint32_t p0 = vox_start[slots[h].vox_base], p1 = vox_start[slots[h].vox_base + slots[h].nvox];
+  slots[h].pt_start = p0;
+  slots[h].npts = p1 - p0;
+  uint32_t run = 0;
+  for (int w = 0; w < 16; w++) {
+    bpref[(size_t)h * 16 + w] = (uint16_t)run;
+    run += (uint32_t)__popc(bmask[(size_t)h * 16 + w]);
+  }
+}
+
+// points into sorted order, tagged with (brick slot << 9 | voxel-in-brick)
+__global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ keys, uint32_t n,
+                                const BrickSlot* __restrict__ slots, uint32_t mask, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t j = idx[i];
-  float4 p = in[j];
-  p.w = __int_as_float((int)j);
+  const uint64_t bkey = keys[i] >> 9;
+  const int bx = (int)(bkey >> 36) - kBrickBias, by = (int)((bkey >> 18) & 0x3ffff) - kBrickBias, bz = (int)(bkey & 0x3ffff) - kBrickBias;
+  uint32_t h = hash_coord(bx, by, bz) & mask;
+  while (slots[h].key != bkey) h = (h + 1) & mask;
+  float4 p = in[idx[i]];
+  p.w = __int_as_float((int)((h << 9) | (uint32_t)(keys[i] & 511u)));
   out[i] = p;
 }
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Build the voxel hash of `cloud` into `map`.  One host sync (voxel count -> table size).
+// Build the voxel hash of `cloud` into `map`.  One host sync (voxel / brick counts -> array sizes).
 int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, TargetMap* map, std::string* err) {
   map->release();
   if (n == 0) { *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
   uint64_t *keys = nullptr, *keys_s = nullptr;
-  uint32_t *idx = nullptr, *idx_s = nullptr;
-  int* d_flags = nullptr;  // [0] out-of-range flag, [1] voxel count
-  void* tmp = nullptr;
-  size_t tmp_bytes = 0;
+  uint32_t *idx = nullptr, *idx_s = nullptr, *vflag = nullptr, *vrank = nullptr;
+  int* d_flags = nullptr;  // [0] out-of-range flag, [1] brick count
+  void *tmp = nullptr, *tmp2 = nullptr;
+  size_t tmp_bytes = 0, tmp2_bytes = 0;
   int rc = PCM_OK;
   const float inv_res = (float)(1.0 / res);  // ivox3d.h:67  inv_resolution_ = 1.0 / resolution_ (float)
 #define CK(x)                                                                    \
@@ -106,33 +158,53 @@ int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float 
   CK(hipMalloc(&keys_s, sizeof(uint64_t) * n));
   CK(hipMalloc(&idx, sizeof(uint32_t) * n));
   CK(hipMalloc(&idx_s, sizeof(uint32_t) * n));
+  CK(hipMalloc(&vflag, sizeof(uint32_t) * n));
+  CK(hipMalloc(&vrank, sizeof(uint32_t) * n));
   CK(hipMalloc(&d_flags, 2 * sizeof(int)));
   CK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), stream));
-  k_voxel_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, res, inv_res, coord_mode, keys, idx, d_flags);
+  k_point_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, res, inv_res, coord_mode, keys, idx, d_flags);
   CK(hipGetLastError());
   CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
   CK(hipMalloc(&tmp, tmp_bytes));
   CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
-  k_count_heads<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, n, reinterpret_cast<unsigned int*>(d_flags + 1));
+  k_head_flags<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, n, vflag, reinterpret_cast<unsigned int*>(d_flags + 1));
   CK(hipGetLastError());
-  int h_flags[2];
-  CK(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
-  CK(hipStreamSynchronize(stream));
-  if (h_flags[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
+  CK(rocprim::exclusive_scan(nullptr, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+  CK(hipMalloc(&tmp2, tmp2_bytes));
+  CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
   {
-    const uint32_t nvox = (uint32_t)h_flags[1];
+    int h_flags[2];
+    uint32_t h_last[2];
+    CK(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&h_last[0], vrank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&h_last[1], vflag + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    if (h_flags[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
+    const uint32_t nvox = h_last[0] + h_last[1];
+    const uint32_t nbricks = (uint32_t)h_flags[1];
     uint32_t cap = 1024;
-    while (cap < 4ull * nvox) cap <<= 1;
-    CK(hipMalloc(&map->slots, sizeof(Slot) * (size_t)cap));
+    while (cap < 4ull * nbricks) cap <<= 1;
+    if (cap > kMaxBrickSlots) { *err = "too many occupied bricks for the 22-bit voxel tag"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
+    CK(hipMalloc(&map->bricks, sizeof(BrickSlot) * (size_t)cap));
+    CK(hipMalloc(&map->bmask, sizeof(uint32_t) * 16 * (size_t)cap));
+    CK(hipMalloc(&map->bpref, sizeof(uint16_t) * 16 * (size_t)cap));
+    CK(hipMalloc(&map->vox_start, sizeof(uint32_t) * ((size_t)nvox + 1)));
     CK(hipMalloc(&map->pts, sizeof(float4) * (size_t)n));
-    CK(hipMemsetAsync(map->slots, 0xFF, sizeof(Slot) * (size_t)cap, stream));
-    k_insert_voxels<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, n, map->slots, cap - 1);
+    CK(hipMemsetAsync(map->bricks, 0xFF, sizeof(BrickSlot) * (size_t)cap, stream));
+    CK(hipMemsetAsync(map->bmask, 0, sizeof(uint32_t) * 16 * (size_t)cap, stream));
+    CK(hipMemsetAsync(map->bpref, 0, sizeof(uint16_t) * 16 * (size_t)cap, stream));
+    k_insert_bricks<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, vrank, n, map->bricks, cap - 1);
     CK(hipGetLastError());
-    k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, n, map->pts);
+    k_fill_voxels<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, vflag, vrank, n, nvox, map->vox_start, map->bricks, map->bmask, cap - 1);
+    CK(hipGetLastError());
+    k_finalize_bricks<<<cdiv(cap, 256), 256, 0, stream>>>(map->bricks, map->bmask, map->bpref, map->vox_start, cap);
+    CK(hipGetLastError());
+    k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, keys_s, n, map->bricks, cap - 1, map->pts);
     CK(hipGetLastError());
     CK(hipStreamSynchronize(stream));
     map->cap = cap;
     map->num_voxels = nvox;
+    map->num_bricks = nbricks;
     map->num_points = n;
     map->res = res;
     map->inv_res = inv_res;
@@ -140,7 +212,7 @@ int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float 
     map->valid = true;
   }
 done:
-  hipFree(keys); hipFree(keys_s); hipFree(idx); hipFree(idx_s); hipFree(d_flags); hipFree(tmp);
+  hipFree(keys); hipFree(keys_s); hipFree(idx); hipFree(idx_s); hipFree(vflag); hipFree(vrank); hipFree(d_flags); hipFree(tmp); hipFree(tmp2);
   if (rc != PCM_OK) map->release();
   return rc;
 #undef CK
