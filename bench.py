@@ -190,7 +190,7 @@ def main():
     value = total_regs / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # roofline of the dominant kernel (k_corr_search): algorithmic bytes per point-iteration
+    # roofline of the dominant kernel (k_linearize): algorithmic bytes per point-iteration
     # = query float4 + 27 hash slots + K-bar candidate float4s  (SURVEY.md §8d, P2PLANE exact 5-NN row)
     b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
     launches = max(1, st["linearize_launches"])
@@ -223,7 +223,7 @@ def main():
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_corr_search", "avg_launch_ms": avg_launch_ms,
+                         "traffic": traffic, "kernel": "k_linearize", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_point_pass": b_pi, "candidates_per_point": kbar, "slots_probed_per_point": probes,
                          "point_passes_per_launch": st["point_passes"] / launches,
                          "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]),

@@ -40,6 +40,12 @@
 namespace pcm {
 
 // neighbour cells in the reference's order (ivox3d.h:211-235): CENTER, NEARBY6, NEARBY18, NEARBY26 are prefixes
+// (compile-time copy for the unrolled LDS search: the offsets become immediates)
+constexpr int kNearby[27][3] = {
+  {0, 0, 0},   {-1, 0, 0},  {1, 0, 0},   {0, 1, 0},   {0, -1, 0},  {0, 0, -1},  {0, 0, 1},
+  {1, 1, 0},   {-1, 1, 0},  {1, -1, 0},  {-1, -1, 0}, {1, 0, 1},   {-1, 0, 1},  {1, 0, -1},
+  {-1, 0, -1}, {0, 1, 1},   {0, -1, 1},  {0, 1, -1},  {0, -1, -1}, {1, 1, 1},   {-1, 1, 1},
+  {1, -1, 1},  {1, 1, -1},  {-1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, -1, -1}};
 __constant__ int8_t c_nearby[27][4] = {
   {0, 0, 0, 0},   {-1, 0, 0, 0},  {1, 0, 0, 0},   {0, 1, 0, 0},   {0, -1, 0, 0},  {0, 0, -1, 0},  {0, 0, 1, 0},
   {1, 1, 0, 0},   {-1, 1, 0, 0},  {1, -1, 0, 0},  {-1, -1, 0, 0}, {1, 0, 1, 0},   {-1, 0, 1, 0},  {1, 0, -1, 0},
@@ -152,6 +158,87 @@ __device__ inline void knn_global(const TargetView& tg, const float (&q)[3], int
   }
 }
 
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// End of a round, one 1024-thread workgroup per pair: fixed-order sum of the
+// round's partial rows (deterministic: 32 row groups x 32 columns, then a serial
+// sum of the 32 group totals) + the GN/LM state machine, or the export of the
+// sums for the parity hooks.  The pair's status byte for this round goes straight
+// to mapped pinned host memory (a posted write), which is all the host polls.
+// (Doing this in the last-arriving workgroup of the residual kernel was tried and
+// lost: the per-workgroup agent-scope release fence cost more than this launch.)
+// grid = npairs, block = 1024
+// ---------------------------------------------------------------------------
+__device__ inline void unpack_sums(const double* s, double* H, double* b, double* cost, int* inliers) {
+  int t = 0;
+  for (int a = 0; a < 6; a++) {
+    for (int c = a; c < 6; c++) { H[a * 6 + c] = s[t]; H[c * 6 + a] = s[t]; t++; }
+  }
+  for (int a = 0; a < 6; a++) b[a] = s[21 + a];
+  *cost = s[27];
+  *inliers = (int)s[28];
+}
+
+__global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restrict__ descs, PairState* __restrict__ states, KernelParams kp, LsqParams lp, int trial_round,
+                                                       int write_flags, unsigned char* __restrict__ flags_row, double* __restrict__ sums_out) {
+  const int pair = blockIdx.x;
+  const int mode = states[pair].mode;
+  if (mode == (trial_round ? MODE_TRIAL : MODE_LINEARIZE)) {
+    __shared__ double s_grp[32 * kPartialStride];
+    __shared__ double s_tot[kPartialStride];
+    const PairDesc d = descs[pair];
+    const uint32_t per = trial_round ? (uint32_t)kp.points_per_block : 256u;
+    const int nblocks = (int)((d.src.num_points + per - 1u) / per);
+    const int j = threadIdx.x & 31, r = threadIdx.x >> 5;
+    double v = 0.0;
+    if (j < kNumSums) {
+      int b = r;
+      for (; b + 96 < nblocks; b += 128) {   // 4 independent loads in flight
+        const double v0 = gload_d(d.partials + (size_t)b * kPartialStride + j), v1 = gload_d(d.partials + (size_t)(b + 32) * kPartialStride + j),
+                     v2 = gload_d(d.partials + (size_t)(b + 64) * kPartialStride + j), v3 = gload_d(d.partials + (size_t)(b + 96) * kPartialStride + j);
+        v = (((v + v0) + v1) + v2) + v3;
+      }
+      for (; b < nblocks; b += 32) v += gload_d(d.partials + (size_t)b * kPartialStride + j);
+    }
+    s_grp[r * kPartialStride + j] = v;
+    __syncthreads();
+    if (threadIdx.x < kNumSums) {
+      double t = 0.0;
+      for (int k = 0; k < 32; k++) t += s_grp[k * kPartialStride + threadIdx.x];
+      s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (kp.do_step) {
+        PairState& st = states[pair];
+        if (mode == MODE_LINEARIZE) {
+          double H[36], b[6], cost;
+          int inl;
+          unpack_sums(s_tot, H, b, &cost, &inl);
+          after_linearize(st, lp, H, b, cost, inl);
+        } else {
+          after_trial(st, lp, s_tot[27]);
+        }
+      } else {
+        for (int k = 0; k < kNumSums; k++) sums_out[pair * kPartialStride + k] = s_tot[k];
+      }
+    }
+  }
+  // status of EVERY pair after the last step launch of the round: 1 = still active, 2 = done
+  if (write_flags && threadIdx.x == 0)
+    __hip_atomic_store(flags_row + pair, (unsigned char)(states[pair].mode != MODE_DONE ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
+                         bool write_flags, unsigned char* d_flags_row, double* d_sums) {
+  k_finish_round<<<npairs, 1024, 0, stream>>>(d_descs, d_states, kp, lp, trial_round ? 1 : 0, write_flags ? 1 : 0, d_flags_row, d_sums);
+}
+
 // ---------------------------------------------------------------------------
 // k_corr_search: grid = (tiles_per_pair, npairs), block = 256, one scan point per lane
 // ---------------------------------------------------------------------------
@@ -169,9 +256,9 @@ constexpr uint16_t kNoCell = 0xffffu;
     t_prev = t_now;                                                            \
   }
 
-template <bool STATS, bool TIMING>
-__global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
-                                                     unsigned long long* __restrict__ stats) {
+template <bool STATS, bool TIMING, bool WRITE_PLANES>
+__global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
+                                                      unsigned long long* __restrict__ stats) {
   const int pair = blockIdx.y;
   if (states[pair].mode != MODE_LINEARIZE) return;
   const PairDesc d = descs[pair];
@@ -342,19 +429,32 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
       PCM_STAMP(3)   // cell grid
       // ---- per-lane 27-cell / 5-NN search out of LDS (reference cell order) ----------------------
       if (search) {
-        const int rx = cx - ox0, ry = cy - oy0, rz = cz - oz0;
-        for (int g = 0; g < kp.num_neighbors; g++) {
-          const int cell = ((rx + c_nearby[g][0]) * Dy + (ry + c_nearby[g][1])) * Dz + (rz + c_nearby[g][2]);
-          uint32_t k = s_cell[cell];
-          if (k == kNoCell) continue;
-          float4 mp = s_pts[k];
-          const int tag = __float_as_int(mp.w);
-          for (;;) {   // the voxel's points: consecutive staged points with the same tag
-            if (STATS) n_cand++;
-            best_offer(best, mp, q, k, kp.max_range_sq);
-            if (++k >= total) break;
-            mp = s_pts[k];
-            if (__float_as_int(mp.w) != tag) break;
+        // all 27 cell heads first (independent LDS reads, one wait), then the occupied cells in
+        // reference order; inside a voxel the next staged point is fetched while the current one
+        // is offered, so a candidate costs one overlapped LDS read instead of two serial ones
+        const int DyDz = Dy * Dz;
+        const int cell0 = ((cx - ox0) * Dy + (cy - oy0)) * Dz + (cz - oz0);
+        uint16_t kh[27];
+#pragma unroll
+        for (int g = 0; g < 27; g++) {
+          kh[g] = kNoCell;
+          if (g < kp.num_neighbors) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
+        }
+        const uint32_t last = total - 1;
+#pragma unroll
+        for (int g = 0; g < 27; g++) {
+          if (kh[g] != kNoCell) {
+            uint32_t k = kh[g];
+            float4 mp = s_pts[k];
+            const int tag = __float_as_int(mp.w);
+            for (;;) {
+              const float4 nx = s_pts[k < last ? k + 1 : last];
+              if (STATS) n_cand++;
+              best_offer(best, mp, q, k, kp.max_range_sq);
+              if (k >= last || __float_as_int(nx.w) != tag) break;
+              mp = nx;
+              k++;
+            }
           }
         }
       }
@@ -368,8 +468,9 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
   // 3- and 4-neighbour cases (double path) are queued and solved by the first lanes
   // of the workgroup afterwards, so one straggler does not drag its whole wave
   // through the double-precision QR.
+  float4 pl = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+  uint32_t my_job = ~0u;
   if (live) {
-    float4 pl = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
     if (best.m == K) {
       float px[K], py[K], pz[K];
 #pragma unroll
@@ -380,17 +481,17 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
       float4 fit;
       if (esti_plane(px, py, pz, K, kp.plane_threshold, &fit)) pl = fit;
     } else if (best.m >= KMIN) {
-      const uint32_t job = atomicAdd(&s_njobs, 1u);
-      s_job[job] = threadIdx.x | ((uint32_t)best.m << 16);
+      my_job = atomicAdd(&s_njobs, 1u);
+      s_job[my_job] = threadIdx.x | ((uint32_t)best.m << 16);
 #pragma unroll
-      for (int j = 0; j < 4; j++) s_jobid[job][j] = best.i[j];
+      for (int j = 0; j < 4; j++) s_jobid[my_job][j] = best.i[j];
     }
-    gstore4(d.planes + i, pl);
   }
   PCM_STAMP(5)   // float plane fit
   __syncthreads();
-  for (uint32_t job = threadIdx.x; job < s_njobs; job += 256) {
-    const uint32_t owner = s_job[job] & 0xffffu, m = s_job[job] >> 16;
+  const uint32_t njobs = s_njobs;
+  for (uint32_t job = threadIdx.x; job < njobs; job += 256) {
+    const uint32_t m = s_job[job] >> 16;
     float px[K], py[K], pz[K];
 #pragma unroll
     for (int j = 0; j < K; j++) {
@@ -399,9 +500,62 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
       px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
     }
     float4 fit;
-    if (esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) gstore4(d.planes + blockIdx.x * 256u + owner, fit);
+    if (!esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) fit.x = __builtin_nanf("");
+    s_jobid[job][0] = __float_as_uint(fit.x); s_jobid[job][1] = __float_as_uint(fit.y);   // hand the plane back to its owner lane
+    s_jobid[job][2] = __float_as_uint(fit.z); s_jobid[job][3] = __float_as_uint(fit.w);
   }
-  PCM_STAMP(6)   // queued double-precision fits
+  __syncthreads();   // also: nobody reads s_pts after this point (its memory is re-used below)
+  if (my_job != ~0u) pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
+
+  // ---- residual / Jacobian of this lane's point, 28 unique normal-equation terms -------------------
+  double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double e = 0.0, one = 0.0;
+  if (live) {
+    bool sel = !(pl.x != pl.x);
+    if (sel) {
+      const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
+      const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+      sel = pn > 81.f * pd2 * pd2;                                       // :631
+      if (sel) {
+        // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
+        J[0] = (double)(q[1] * pl.z - q[2] * pl.y);
+        J[1] = (double)(q[2] * pl.x - q[0] * pl.z);
+        J[2] = (double)(q[0] * pl.y - q[1] * pl.x);
+        J[3] = (double)pl.x; J[4] = (double)pl.y; J[5] = (double)pl.z;
+        e = (double)pd2;
+        one = 1.0;
+      }
+    }
+    if (WRITE_PLANES) gstore4(d.planes + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
+  }
+  // wave reduce -> LDS -> one partial row per workgroup (the LDS of s_pts is free now).
+  // Each product is formed and reduced on the spot so only J, e stay live.
+  double* s_red64 = reinterpret_cast<double*>(s_pts);   // [4][32] wave partials, then [9][32] scratch of finish_round
+  {
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int c = a; c < 6; c++) {
+        const double v = wave_sum(J[a] * J[c]);
+        if (lane == 0) s_red64[wave * kPartialStride + t] = v;
+        t++;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      const double v = wave_sum(J[a] * e);
+      if (lane == 0) s_red64[wave * kPartialStride + 21 + a] = v;
+    }
+    const double vc = wave_sum(e * e), vn = wave_sum(one);
+    if (lane == 0) { s_red64[wave * kPartialStride + 27] = vc; s_red64[wave * kPartialStride + 28] = vn; }
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums) {
+    const double v = ((s_red64[threadIdx.x] + s_red64[kPartialStride + threadIdx.x]) + s_red64[2 * kPartialStride + threadIdx.x]) + s_red64[3 * kPartialStride + threadIdx.x];
+    gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+  }
+  PCM_STAMP(6)   // queued double-precision fits + residual + workgroup reduction
   if (TIMING && threadIdx.x == 0) atomicAdd(&stats[15], 1ull);
   if (STATS) {
     unsigned long long c = n_cand, pr = n_probe;
@@ -415,160 +569,59 @@ __global__ void __launch_bounds__(256) k_corr_search(const PairDesc* __restrict_
   }
 }
 
-void launch_corr_search(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, unsigned long long* d_stats,
-                        bool timing) {
+void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
+                      unsigned long long* d_stats, bool timing) {
   dim3 grid((unsigned)kp.tiles_per_pair, (unsigned)npairs);
-  if (d_stats && timing) k_corr_search<false, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
-  else if (d_stats) k_corr_search<true, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
-  else k_corr_search<false, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats);
+#define PCM_LAUNCH(S, T, W) k_linearize<S, T, W><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats)
+  if (d_stats && timing) { if (write_planes) PCM_LAUNCH(false, true, true); else PCM_LAUNCH(false, true, false); }
+  else if (d_stats) { if (write_planes) PCM_LAUNCH(true, false, true); else PCM_LAUNCH(true, false, false); }
+  else { if (write_planes) PCM_LAUNCH(false, false, true); else PCM_LAUNCH(false, false, false); }
+#undef PCM_LAUNCH
 }
 
 // ---------------------------------------------------------------------------
-// k_residual_reduce: LINEARIZE -> H, b, cost, #inliers of the planes fitted by
-// k_corr_search; TRIAL -> cost of the same correspondences at the trial pose
-// (compute_error contract, fast_gicp_impl.hpp:213-237).
+// k_trial: cost of the correspondences (planes) of the last linearize at the LM
+// trial pose -- the compute_error contract (fast_gicp_impl.hpp:213-237).
 // grid = (blocks_per_pair, npairs), block = 256
 // ---------------------------------------------------------------------------
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-template <bool WRITE_SEL>
-__global__ void __launch_bounds__(256) k_residual_reduce(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
+__global__ void __launch_bounds__(256) k_trial(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
   const int pair = blockIdx.y;
-  const int mode = states[pair].mode;
-  if (mode == MODE_DONE) return;
+  if (states[pair].mode != MODE_TRIAL) return;
   const PairDesc d = descs[pair];
-  const PoseF P = load_pose(mode == MODE_LINEARIZE ? states[pair].x0 : states[pair].xi);
-
-  double acc[kNumSums];
-#pragma unroll
-  for (int j = 0; j < kNumSums; j++) acc[j] = 0.0;
-
   const uint32_t begin = blockIdx.x * (uint32_t)kp.points_per_block;
+  if (begin >= d.src.num_points) return;
+  const PoseF P = load_pose(states[pair].xi);
   uint32_t end = begin + (uint32_t)kp.points_per_block;
   end = end < d.src.num_points ? end : d.src.num_points;
-
+  double cost = 0.0, cnt = 0.0;
   for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
     const float4 pl = gload4(d.planes + i);
-    if (pl.x != pl.x) continue;  // no plane / not selected
+    if (pl.x != pl.x) continue;  // not selected by the last linearize
     const float4 p = gload4(d.src.pts + i);
     float q[3];
     transform(P, p, q);
-    const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
+    const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
     const double e = (double)pd2;
-    if (mode == MODE_LINEARIZE) {
-      const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
-      const bool sel = pn > 81.f * pd2 * pd2;                          // :631
-      if (!sel) {
-        if (WRITE_SEL) gstore_f(&d.planes[i].x, __builtin_nanf(""));            // dropped for the following trial passes too
-        continue;
-      }
-      // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
-      const float jf[6] = {q[1] * pl.z - q[2] * pl.y, q[2] * pl.x - q[0] * pl.z, q[0] * pl.y - q[1] * pl.x, pl.x, pl.y, pl.z};
-      double J[6];
-#pragma unroll
-      for (int a = 0; a < 6; a++) J[a] = (double)jf[a];
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < 6; a++) {
-#pragma unroll
-        for (int c = a; c < 6; c++) { acc[t] = fma(J[a], J[c], acc[t]); t++; }
-      }
-#pragma unroll
-      for (int a = 0; a < 6; a++) acc[21 + a] = fma(J[a], e, acc[21 + a]);
-    }
-    acc[27] = fma(e, e, acc[27]);
-    acc[28] += 1.0;
+    cost = fma(e, e, cost);
+    cnt += 1.0;
   }
-
-  // wave reduce -> LDS -> one partial row per workgroup
-  __shared__ double s_part[4][kPartialStride];
+  __shared__ double s_red64[4 * kPartialStride];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < kNumSums; j++) {
-    const double v = wave_sum(acc[j]);
-    if (lane == 0) s_part[wave][j] = v;
-  }
+  cost = wave_sum(cost);
+  cnt = wave_sum(cnt);
+  if (threadIdx.x < 4 * kPartialStride) s_red64[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (lane == 0) { s_red64[wave * kPartialStride + 27] = cost; s_red64[wave * kPartialStride + 28] = cnt; }
   __syncthreads();
   if (threadIdx.x < kNumSums) {
-    const double v = ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
+    const double v = ((s_red64[threadIdx.x] + s_red64[kPartialStride + threadIdx.x]) + s_red64[2 * kPartialStride + threadIdx.x]) + s_red64[3 * kPartialStride + threadIdx.x];
     gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
   }
 }
 
-void launch_residual(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_sel) {
+void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs) {
   dim3 grid((unsigned)kp.blocks_per_pair, (unsigned)npairs);
-  if (write_sel) k_residual_reduce<true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
-  else k_residual_reduce<false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
-}
-
-// ---------------------------------------------------------------------------
-// second stage: fixed-order sum of the workgroup partials + GN/LM state machine
-// grid = npairs, block = 256
-// ---------------------------------------------------------------------------
-__device__ inline void sum_partials(const double* __restrict__ partials, int blocks_per_pair, double* s_sum /* [8][32] then [0][*] holds the result */) {
-  const int j = threadIdx.x & 31, r = threadIdx.x >> 5;  // 8 row groups x 32 columns
-  double v = 0.0;
-  if (j < kNumSums) {
-    for (int b = r; b < blocks_per_pair; b += 8) v += gload_d(partials + (size_t)b * kPartialStride + j);
-  }
-  s_sum[r * kPartialStride + j] = v;
-  __syncthreads();
-  if (threadIdx.x < kNumSums) {
-    double t = 0.0;
-    for (int k = 0; k < 8; k++) t += s_sum[k * kPartialStride + threadIdx.x];
-    s_sum[8 * kPartialStride + threadIdx.x] = t;
-  }
-  __syncthreads();
-}
-
-__device__ inline void unpack_sums(const double* s, double* H, double* b, double* cost, int* inliers) {
-  int t = 0;
-  for (int a = 0; a < 6; a++) {
-    for (int c = a; c < 6; c++) { H[a * 6 + c] = s[t]; H[c * 6 + a] = s[t]; t++; }
-  }
-  for (int a = 0; a < 6; a++) b[a] = s[21 + a];
-  *cost = s[27];
-  *inliers = (int)s[28];
-}
-
-__global__ void __launch_bounds__(256) k_lsq_step(const PairDesc* __restrict__ descs, PairState* __restrict__ states, LsqParams lp, int blocks_per_pair,
-                                                  int* __restrict__ active_slot) {
-  const int pair = blockIdx.x;
-  __shared__ double s_sum[9 * kPartialStride];
-  const int mode = states[pair].mode;
-  if (mode == MODE_DONE) return;
-  sum_partials(descs[pair].partials, blocks_per_pair, s_sum);
-  if (threadIdx.x == 0) {
-    const double* s = s_sum + 8 * kPartialStride;
-    PairState& st = states[pair];
-    if (mode == MODE_LINEARIZE) {
-      double H[36], b[6], cost;
-      int inl;
-      unpack_sums(s, H, b, &cost, &inl);
-      after_linearize(st, lp, H, b, cost, inl);
-    } else {
-      after_trial(st, lp, s[27]);
-    }
-    if (st.mode != MODE_DONE) atomicAdd(active_slot, 1);
-  }
-}
-
-void launch_lsq_step(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const LsqParams& lp, int blocks_per_pair, int npairs, int* d_active_slot) {
-  k_lsq_step<<<npairs, 256, 0, stream>>>(d_descs, d_states, lp, blocks_per_pair, d_active_slot);
-}
-
-__global__ void __launch_bounds__(256) k_reduce_only(const PairDesc* __restrict__ descs, int blocks_per_pair, double* __restrict__ sums) {
-  __shared__ double s_sum[9 * kPartialStride];
-  sum_partials(descs[blockIdx.x].partials, blocks_per_pair, s_sum);
-  if (threadIdx.x < kNumSums) sums[blockIdx.x * kPartialStride + threadIdx.x] = s_sum[8 * kPartialStride + threadIdx.x];
-}
-
-void launch_reduce_only(hipStream_t stream, const PairDesc* d_descs, int blocks_per_pair, int npairs, double* d_sums) {
-  k_reduce_only<<<npairs, 256, 0, stream>>>(d_descs, blocks_per_pair, d_sums);
+  k_trial<<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
 }
 
 __global__ void k_init_states(PairState* __restrict__ states, const float* __restrict__ guesses, int npairs, int max_iterations) {

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -38,8 +39,9 @@ struct Workspace {
   pcm_result* d_results = nullptr;
   double* d_partials = nullptr;
   double* d_sums = nullptr;
-  int* d_active = nullptr;
-  int* h_active = nullptr;  // pinned
+  unsigned char* d_flags = nullptr;  // device view of h_flags
+  unsigned char* h_flags = nullptr;  // mapped pinned host memory: [round][pair] status bytes written by k_finish_round
+  size_t cap_flags = 0;
   unsigned long long* d_stats = nullptr;
   SortJob* d_jobs = nullptr;
   SortScratch sort;
@@ -73,11 +75,15 @@ int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, i
     HIPCK(c, hipMalloc(&w.d_partials, sizeof(double) * partial_doubles));
     w.cap_partials = partial_doubles;
   }
-  if (rounds > w.cap_rounds) {
-    if (w.d_active) { hipFree(w.d_active); hipHostFree(w.h_active); }
-    HIPCK(c, hipMalloc(&w.d_active, sizeof(int) * rounds));
-    HIPCK(c, hipHostMalloc(&w.h_active, sizeof(int) * rounds));
-    w.cap_rounds = rounds;
+  if ((size_t)rounds * (size_t)std::max(npairs, 64) > w.cap_flags) {
+    if (w.h_flags) hipHostFree(w.h_flags);
+    w.h_flags = nullptr; w.cap_flags = 0;
+    const size_t bytes = (size_t)rounds * (size_t)std::max(npairs, 64);
+    // per-round status bytes of every pair live in mapped pinned host memory: k_finish_round
+    // stores them directly (posted writes); the host polls them, no event / copy per round
+    HIPCK(c, hipHostMalloc(reinterpret_cast<void**>(&w.h_flags), bytes, hipHostMallocMapped));
+    HIPCK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&w.d_flags), w.h_flags, 0));
+    w.cap_flags = bytes;
   }
   if (!w.d_stats) HIPCK(c, hipMalloc(&w.d_stats, sizeof(unsigned long long) * 16));
   while ((int)w.ev_round.size() < 2) {
@@ -139,6 +145,11 @@ int prepare(pcm_ctx* c) {
     HIPCK(c, hipMalloc(&c->src_order, sizeof(float4) * c->src.n));
     c->src_order_cap = c->src.n;
   }
+  if (!c->counter) {
+    HIPCK(c, hipMalloc(&c->counter, sizeof(unsigned int)));
+    HIPCK(c, hipMemsetAsync(c->counter, 0, sizeof(unsigned int), c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+  }
   if (c->planes_cap < c->src.n) {
     if (c->planes) hipFree(c->planes);
     c->planes = nullptr; c->planes_cap = 0;
@@ -181,6 +192,7 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->src.num_points = (uint32_t)c->src.n;
   d->planes = c->planes;
   d->partials = partials;
+  d->counter = c->counter;
 }
 
 KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
@@ -199,6 +211,7 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.points_per_block = geom.points_per_block;
   kp.tiles_per_pair = geom.tiles_per_pair;
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
+  kp.do_step = 1;
   return kp;
 }
 
@@ -243,7 +256,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   const KernelParams kp = kernel_params(g, geom);
   // worst case: every outer iteration = 1 linearize + lm_max_iterations trials
   const int max_rounds = std::max(1, g.max_iterations) * (g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT ? 1 + std::max(1, g.lm_max_iterations) : 1) + 1;
-  const size_t per_pair_partials = (size_t)geom.blocks_per_pair * kPartialStride;
+  const size_t per_pair_partials = (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride;
   Workspace* w = nullptr;
   int rc = ensure_ws(c0, &w, n, per_pair_partials * n, max_rounds);
   if (rc != PCM_OK) return rc;
@@ -271,13 +284,14 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   std::vector<PairDesc> descs(n);
   for (int i = 0; i < n; i++) fill_desc(ctxs[i], &descs[i], w->d_partials + per_pair_partials * i);
   HIPCK(c0, hipMemcpyAsync(w->d_descs, descs.data(), sizeof(PairDesc) * n, hipMemcpyHostToDevice, st));
-  HIPCK(c0, hipMemsetAsync(w->d_active, 0, sizeof(int) * max_rounds, st));
+  std::memset(w->h_flags, 0, (size_t)max_rounds * n);
   launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations);
   const bool stats_on = (c0->profiling & 1) != 0;      // HIP events around the residual launches
   const bool timing_on = (c0->profiling & 4) != 0;     // diagnostic: in-kernel phase stamps (stats.phase_cycles)
   const bool counters_on = (c0->profiling & 2) != 0 || timing_on;   // kNN candidate / probe counters (slower kernel variant)
   if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 16, st));
-  const bool write_sel = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;  // trial passes re-use the selected set
+  const bool is_lm = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;
+  const bool write_sel = is_lm;  // trial passes re-use the planes of the selected set
 
   int rounds_done = 0;
   size_t prof_used = 0;
@@ -286,17 +300,32 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       while (w->ev_prof.size() < prof_used + 3) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
       HIPCK(c0, hipEventRecord(w->ev_prof[prof_used], st));
     }
-    launch_corr_search(st, w->d_descs, w->d_states, kp, n, counters_on ? w->d_stats : nullptr, timing_on);
+    // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
+    // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
+    launch_linearize(st, w->d_descs, w->d_states, kp, n, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
-    launch_residual(st, w->d_descs, w->d_states, kp, n, write_sel);
+    launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums);
+    if (is_lm) {
+      launch_trial(st, w->d_descs, w->d_states, kp, n);
+      launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, true, true, w->d_flags + (size_t)r * n, w->d_sums);
+    }
     if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st)); prof_used += 3; }
-    launch_lsq_step(st, w->d_descs, w->d_states, lp, geom.blocks_per_pair, n, w->d_active + r);
-    HIPCK(c0, hipMemcpyAsync(w->h_active + r, w->d_active + r, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCK(c0, hipEventRecord(w->ev_round[r & 1], st));
     rounds_done = r + 1;
     if (r >= 1) {  // look one round behind so the GPU always has the next round queued
-      HIPCK(c0, hipEventSynchronize(w->ev_round[(r - 1) & 1]));
-      if (w->h_active[r - 1] == 0) break;
+      volatile unsigned char* row = w->h_flags + (size_t)(r - 1) * n;
+      bool any_active = false;
+      const auto t_start = std::chrono::steady_clock::now();
+      for (int i = 0; i < n; i++) {
+        unsigned spins = 0;
+        while (row[i] == 0) {   // the round's status byte of pair i has not landed yet
+          if ((++spins & 0xfff) == 0) {
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) { c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
+            if (hipStreamQuery(st) == hipSuccess && row[i] == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
+          }
+        }
+        any_active |= row[i] == 1;
+      }
+      if (!any_active) break;
     }
   }
   HIPCK(c0, hipGetLastError());
@@ -348,7 +377,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   const Geom geom = pick_geom(c->src.n, 1);
   const KernelParams kp = kernel_params(c->cfg, geom);
   Workspace* w = nullptr;
-  rc = ensure_ws(c, &w, 1, (size_t)geom.blocks_per_pair * kPartialStride, 2);
+  rc = ensure_ws(c, &w, 1, (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride, 2);
   if (rc != PCM_OK) return rc;
   PairDesc d;
   fill_desc(c, &d, w->d_partials);
@@ -359,9 +388,11 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   s.mode = linearize ? MODE_LINEARIZE : MODE_TRIAL;
   HIPCK(c, hipMemcpyAsync(w->d_descs, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
   HIPCK(c, hipMemcpyAsync(w->d_states, &s, sizeof(s), hipMemcpyHostToDevice, c->stream));
-  if (linearize) launch_corr_search(c->stream, w->d_descs, w->d_states, kp, 1, nullptr);
-  launch_residual(c->stream, w->d_descs, w->d_states, kp, 1, true);
-  launch_reduce_only(c->stream, w->d_descs, geom.blocks_per_pair, 1, w->d_sums);
+  KernelParams kp1 = kp;
+  kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
+  if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
+  else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
+  launch_finish_round(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, !linearize, false, w->d_flags, w->d_sums);
   HIPCK(c, hipGetLastError());
   HIPCK(c, hipMemcpyAsync(sums, w->d_sums, sizeof(double) * kPartialStride, hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
@@ -427,6 +458,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->src_order) hipFree(c->src_order);
     c->map.release();
     if (c->planes) hipFree(c->planes);
+    if (c->counter) hipFree(c->counter);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   }
   delete c;

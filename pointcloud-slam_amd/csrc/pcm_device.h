@@ -117,7 +117,8 @@ struct PairDesc {
   TargetView tgt;
   SourceView src;
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
-  double* partials;     // [blocks_per_pair][kPartialStride]
+  double* partials;     // [workgroups of the round][kPartialStride]
+  unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)
 };
 
 constexpr int kNumSums = 29;        // 21 (H upper) + 6 (b) + cost + inlier count
@@ -129,10 +130,11 @@ struct KernelParams {
   int32_t min_knn;
   float max_range_sq;         // smallest float >= max_range^2 (see best_offer)
   float plane_threshold;
-  int32_t blocks_per_pair;    // k_residual_reduce grid.x
-  int32_t points_per_block;   // k_residual_reduce points per workgroup
-  int32_t tiles_per_pair;     // k_corr_search grid.x (256-point tiles)
+  int32_t blocks_per_pair;    // k_trial grid.x
+  int32_t points_per_block;   // k_trial points per workgroup
+  int32_t tiles_per_pair;     // k_linearize grid.x (256-point tiles)
   int32_t use_lds;            // 0: always probe the global table per lane (A/B and parity checks)
+  int32_t do_step;            // 1: the last workgroup runs the GN/LM step; 0: it exports the sums (parity hooks)
 };
 
 }  // namespace pcm

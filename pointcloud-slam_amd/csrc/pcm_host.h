@@ -70,11 +70,11 @@ struct LaunchGeom {
   int blocks_per_pair;
   int points_per_block;
 };
-void launch_corr_search(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, unsigned long long* d_stats,
-                        bool timing = false);
-void launch_residual(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_sel);
-void launch_lsq_step(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const LsqParams& lp, int blocks_per_pair, int npairs, int* d_active_slot);
-void launch_reduce_only(hipStream_t stream, const PairDesc* d_descs, int blocks_per_pair, int npairs, double* d_sums /* npairs x 32 */);
+void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
+                      unsigned long long* d_stats, bool timing);
+void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs);
+void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
+                         bool write_flags, unsigned char* d_flags_row, double* d_sums);
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
 
@@ -91,6 +91,7 @@ struct pcm_ctx {
   size_t src_order_cap = 0;
   bool src_sorted = false;       // src_order holds the current source
   float4* planes = nullptr;
+  unsigned int* counter = nullptr;   // round tickets (device, one word)
   size_t planes_cap = 0;
   std::string err;
   pcm_stats stats{};
