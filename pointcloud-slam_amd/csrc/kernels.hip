@@ -46,6 +46,9 @@ constexpr int kNearby[27][3] = {
   {1, 1, 0},   {-1, 1, 0},  {1, -1, 0},  {-1, -1, 0}, {1, 0, 1},   {-1, 0, 1},  {1, 0, -1},
   {-1, 0, -1}, {0, 1, 1},   {0, -1, 1},  {0, 1, -1},  {0, -1, -1}, {1, 1, 1},   {-1, 1, 1},
   {1, -1, 1},  {1, 1, -1},  {-1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, -1, -1}};
+// term j of the normal equations = row[c_term_a[j]] * row[c_term_b[j]] with row = (J0..J5, e, selected)
+__constant__ int8_t c_term_a[32] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 0, 0, 0};
+__constant__ int8_t c_term_b[32] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 0, 0, 0};
 __constant__ int8_t c_nearby[27][4] = {
   {0, 0, 0, 0},   {-1, 0, 0, 0},  {1, 0, 0, 0},   {0, 1, 0, 0},   {0, -1, 0, 0},  {0, 0, -1, 0},  {0, 0, 1, 0},
   {1, 1, 0, 0},   {-1, 1, 0, 0},  {1, -1, 0, 0},  {-1, -1, 0, 0}, {1, 0, 1, 0},   {-1, 0, 1, 0},  {1, 0, -1, 0},
@@ -271,6 +274,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
   __shared__ int s_red[4][6];
   __shared__ int s_box[8];                 // origin xyz, dims xyz, ncell, dense flag
   __shared__ int s_bbox[8];                // first brick xyz, brick dims xyz, nbricks
+  __shared__ int4 s_borg[kCapBricks];      // voxel coordinates of each brick's corner relative to the box origin
   __shared__ uint32_t s_bps[kCapBricks];   // first map point of each brick under the box
   __shared__ uint32_t s_boff[kCapBricks + 1];  // its offset in s_pts (exclusive scan of the point counts)
   __shared__ uint32_t s_njobs;
@@ -362,14 +366,17 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
         const int z = lane % nbz, xy = lane / nbz, y = xy % nby, x = xy / nby;
         const uint64_t key = pack_brick(bx0 + x, by0 + y, bz0 + z);
         uint32_t h = hash_coord(bx0 + x, by0 + y, bz0 + z) & tg.mask;
-        for (;;) {
+        for (;;) {   // both halves of the 32-byte slot in flight together
           const uint4 s0 = gload4u(&tg.bricks[h]);
+          const uint4 s1 = gload4u(reinterpret_cast<const char*>(&tg.bricks[h]) + 16);
           if (STATS) n_probe++;
           const uint64_t sk = slot_key(s0);
-          if (sk == key) { const uint4 s1 = gload4u(reinterpret_cast<const char*>(&tg.bricks[h]) + 16); ps = s1.x; npts = s1.y; break; }
+          if (sk == key) { ps = s1.x; npts = s1.y; break; }
           if (sk == kEmptyKey) break;
           h = (h + 1) & tg.mask;
         }
+        // voxel coordinates of the brick's corner relative to the tile box
+        s_borg[lane] = make_int4(((bx0 + x) << kBrickShift) - ox0, ((by0 + y) << kBrickShift) - oy0, ((bz0 + z) << kBrickShift) - oz0, 0);
       }
       uint32_t incl = npts;
 #pragma unroll
@@ -417,10 +424,9 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
           const int tag = __float_as_int(v[r].w);
           const bool head = k == s_boff[vb[r]] || __float_as_int(s_pts[k - 1].w) != tag;
           if (head) {
-            const int b = vb[r], bz = b % nbz, bxy = b / nbz, by = bxy % nby, bx = bxy / nby;
+            const int4 o = s_borg[vb[r]];
             const int li = tag & 511;
-            const int x = ((bx0 + bx) << kBrickShift) + (li >> 6) - ox0, y = ((by0 + by) << kBrickShift) + ((li >> 3) & 7) - oy0,
-                      z = ((bz0 + bz) << kBrickShift) + (li & 7) - oz0;
+            const int x = o.x + (li >> 6), y = o.y + ((li >> 3) & 7), z = o.z + (li & 7);
             if (x >= 0 && x < Dx && y >= 0 && y < Dy && z >= 0 && z < Dz) s_cell[(x * Dy + y) * Dz + z] = (uint16_t)k;
           }
         }
@@ -507,52 +513,53 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
   __syncthreads();   // also: nobody reads s_pts after this point (its memory is re-used below)
   if (my_job != ~0u) pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
 
-  // ---- residual / Jacobian of this lane's point, 28 unique normal-equation terms -------------------
-  double J[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  double e = 0.0, one = 0.0;
-  if (live) {
-    bool sel = !(pl.x != pl.x);
-    if (sel) {
-      const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
-      const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
-      sel = pn > 81.f * pd2 * pd2;                                       // :631
-      if (sel) {
-        // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
-        J[0] = (double)(q[1] * pl.z - q[2] * pl.y);
-        J[1] = (double)(q[2] * pl.x - q[0] * pl.z);
-        J[2] = (double)(q[0] * pl.y - q[1] * pl.x);
-        J[3] = (double)pl.x; J[4] = (double)pl.y; J[5] = (double)pl.z;
-        e = (double)pd2;
-        one = 1.0;
-      }
-    }
-    if (WRITE_PLANES) gstore4(d.planes + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
-  }
-  // wave reduce -> LDS -> one partial row per workgroup (the LDS of s_pts is free now).
-  // Each product is formed and reduced on the spot so only J, e stay live.
-  double* s_red64 = reinterpret_cast<double*>(s_pts);   // [4][32] wave partials, then [9][32] scratch of finish_round
+  // ---- residual / Jacobian of this lane's point -> one 8-float row in LDS ---------------------------
+  // (the LDS of s_pts is free now: nobody reads map points after the barrier above)
+  float* s_row = reinterpret_cast<float*>(s_pts);                       // [256][8]: J0..J5, e, selected
+  double* s_grp = reinterpret_cast<double*>(s_row + 256 * 8);           // [8][32] group partials
   {
-    int t = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-#pragma unroll
-      for (int c = a; c < 6; c++) {
-        const double v = wave_sum(J[a] * J[c]);
-        if (lane == 0) s_red64[wave * kPartialStride + t] = v;
-        t++;
+    float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      bool sel = !(pl.x != pl.x);
+      if (sel) {
+        const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
+        const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+        sel = pn > 81.f * pd2 * pd2;                                       // :631
+        if (sel) {
+          // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
+          row[0] = q[1] * pl.z - q[2] * pl.y;
+          row[1] = q[2] * pl.x - q[0] * pl.z;
+          row[2] = q[0] * pl.y - q[1] * pl.x;
+          row[3] = pl.x; row[4] = pl.y; row[5] = pl.z;
+          row[6] = pd2;
+          row[7] = 1.f;
+        }
       }
+      if (WRITE_PLANES) gstore4(d.planes + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
     }
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-      const double v = wave_sum(J[a] * e);
-      if (lane == 0) s_red64[wave * kPartialStride + 21 + a] = v;
+    float4* dst = reinterpret_cast<float4*>(s_row + threadIdx.x * 8);
+    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+  }
+  __syncthreads();
+  // ---- 29 sums over the tile's 256 rows: thread (group g, term j) adds 32 rows in double ------------
+  // term j = row[ia] * row[ib]: 21 x H upper triangle, 6 x b = J e, cost = e e, count = sel sel
+  {
+    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double v = 0.0;
+    if (j < kNumSums) {
+      const int ia = c_term_a[j], ib = c_term_b[j];
+      const float* r0 = s_row + (g * 32) * 8;
+#pragma unroll 8
+      for (int k = 0; k < 32; k++) v = fma((double)r0[k * 8 + ia], (double)r0[k * 8 + ib], v);
     }
-    const double vc = wave_sum(e * e), vn = wave_sum(one);
-    if (lane == 0) { s_red64[wave * kPartialStride + 27] = vc; s_red64[wave * kPartialStride + 28] = vn; }
+    s_grp[g * kPartialStride + j] = v;
   }
   __syncthreads();
   if (threadIdx.x < kNumSums) {
-    const double v = ((s_red64[threadIdx.x] + s_red64[kPartialStride + threadIdx.x]) + s_red64[2 * kPartialStride + threadIdx.x]) + s_red64[3 * kPartialStride + threadIdx.x];
+    double v = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
     gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
   }
   PCM_STAMP(6)   // queued double-precision fits + residual + workgroup reduction
