@@ -77,7 +77,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-gpu", type=int, default=16)
+    ap.add_argument("--pairs-per-gpu", type=int, default=32)
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="independent batches in flight per GPU (each on its own stream / host thread), so the few slow-converging "
+                         "pairs of one batch run under the bulk of the next")
     ap.add_argument("--scan-points", type=int, default=100000)
     ap.add_argument("--map-points", type=int, default=1000000)
     ap.add_argument("--optimizer", default="GN", choices=["GN", "LM"])
@@ -135,15 +138,58 @@ def main():
     d_results = torch.zeros(n_local * rec, dtype=torch.uint8, device=dev)
     d_gather = torch.zeros(world * n_local * rec, dtype=torch.uint8, device=dev) if world > 1 else None
 
-    def step():
-        # a registration starts from a NEW scan: hand every object its (HBM-resident)
-        # scan again, so the on-device Morton re-ordering is inside the timed step
-        for r, (d_scan, _) in zip(regs, d_inputs):
-            r.set_input_source(d_scan)
-        res = pcm.align_batch(regs, guesses, device_out=d_results.data_ptr())
-        if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per batch)
-            dist.all_gather_into_tensor(d_gather, d_results)
+    # ---- S independent sub-batches per GPU, each driven by its own host thread on its own stream ----
+    import threading
+    S = max(1, min(args.pipeline, n_local))
+    bounds = [(n_local * j) // S for j in range(S + 1)]
+    groups = [list(range(bounds[j], bounds[j + 1])) for j in range(S)]
+    pgs = [dist.new_group(list(range(world))) for _ in range(S)] if world > 1 else [None] * S   # one RCCL communicator per pipeline slot
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+
+    def sub_step(j):
+        """One pass of the hot path over sub-batch j."""
+        idx = groups[j]
+        lo, hi = idx[0], idx[-1] + 1
+        # a registration starts from a NEW scan: hand every object its (HBM-resident) scan
+        # again, so the on-device Morton re-ordering is inside the timed step
+        for i in idx:
+            regs[i].set_input_source(d_inputs[i][0])
+        res = pcm.align_batch([regs[i] for i in idx], guesses[lo:hi], device_out=d_results.data_ptr() + lo * rec)
+        if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per sub-batch)
+            with torch.cuda.stream(streams[j]):
+                out = d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec]
+                tmp = torch.empty(world * (hi - lo) * rec, dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(tmp, d_results[lo * rec:hi * rec], group=pgs[j])
+                out.copy_(tmp.view(world, (hi - lo) * rec))
+            streams[j].synchronize()
         return res
+
+    def run_steps(k, stagger_s=0.0):
+        """k passes over every sub-batch; sub-batch j starts j*stagger_s late so the tails interleave."""
+        last = [None] * S
+        errs = []
+
+        def worker(j):
+            try:
+                torch.cuda.set_device(local_rank)
+                if stagger_s > 0 and j > 0:
+                    time.sleep(j * stagger_s)
+                for _ in range(k):
+                    last[j] = sub_step(j)
+            except Exception as e:   # surfaced in the main thread
+                errs.append(e)
+
+        if S == 1:
+            worker(0)
+        else:
+            ths = [threading.Thread(target=worker, args=(j,)) for j in range(S)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+        if errs:
+            raise errs[0]
+        return [r for grp in last for r in grp]
 
     def fence():
         torch.cuda.synchronize()
@@ -154,23 +200,28 @@ def main():
     # cold pass: includes voxel-hash build + scan re-ordering (lazy on first align)
     fence()
     t0 = time.perf_counter()
-    res = step()
+    res = run_steps(1)
     fence()
     t_cold = time.perf_counter() - t0
 
-    for _ in range(max(0, args.warmup - 1)):
-        step()
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.warmup - 1)):
+        run_steps(1)
+    fence()
+    t_warm = (time.perf_counter() - t0) / max(1, args.warmup - 1)
 
-    regs[0].reset_stats()
-    regs[0].set_profiling(1)         # HIP events around every residual launch, on the launch stream
+    for j in range(S):
+        regs[groups[j][0]].reset_stats()
+        regs[groups[j][0]].set_profiling(1)         # HIP events around every residual launch, on the launch stream
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps, stagger_s=t_warm / S if S > 1 else 0.0)
     fence()
     elapsed = time.perf_counter() - t0
-    st = regs[0].stats()
-    regs[0].set_profiling(0)
+    sts = [regs[groups[j][0]].stats() for j in range(S)]
+    st = {k: sum(x[k] for x in sts) for k in sts[0]}
+    for j in range(S):
+        regs[groups[j][0]].set_profiling(0)
 
     t = torch.tensor([elapsed, t_cold], dtype=torch.float64, device=dev)
     if world > 1:
@@ -178,11 +229,14 @@ def main():
     elapsed, t_cold = float(t[0]), float(t[1])
 
     # counters pass (untimed): candidates / probes per point for the algorithmic-byte model
-    regs[0].reset_stats()
-    regs[0].set_profiling(3)
-    step()
-    sc = regs[0].stats()
-    regs[0].set_profiling(0)
+    for j in range(S):
+        regs[groups[j][0]].reset_stats()
+        regs[groups[j][0]].set_profiling(3)
+    run_steps(1)
+    scs = [regs[groups[j][0]].stats() for j in range(S)]
+    sc = {k: sum(x[k] for x in scs) for k in scs[0]}
+    for j in range(S):
+        regs[groups[j][0]].set_profiling(0)
     kbar = sc["candidates"] / max(1, sc["point_passes"])
     probes = sc["slots_probed"] / max(1, sc["point_passes"])
 
@@ -218,7 +272,7 @@ def main():
             "dtype": "f32 geometry / f64 accumulate", "data": "synthetic",
             "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence)"
                                    % (args.scan_points, args.map_points, args.optimizer),
-                       "pairs_per_gpu": n_local, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
+                       "pairs_per_gpu": n_local, "batches_in_flight": S, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
                        "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), RCCL all_gather of poses" % world,
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen},

@@ -143,7 +143,11 @@ int pcm_set_stream(pcm_ctx *ctx, void *hip_stream);        /* run on a caller st
 /* setInputTarget / setInputSource  (impl/fast_gicp_impl.hpp:71-90): `tag` is
  * the caller's pointer identity; an equal non-zero tag makes the call a no-op,
  * like the reference's `if (target_ == cloud) return;`.  The library copies
- * the xyz fields into device memory it owns (voxel hash built here). */
+ * the xyz fields into device memory it owns (voxel hash built lazily at the next
+ * align).  One exception, for speed: a SOURCE given as a device buffer with a
+ * 16-byte stride (pcl::PointXYZ layout) is used in place, not copied -- like the
+ * reference's shared_ptr input it must stay alive and unchanged until the
+ * align() that uses it has returned. */
 int pcm_set_target(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory, uint64_t tag);
 int pcm_set_source(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory, uint64_t tag);
 int pcm_swap_source_and_target(pcm_ctx *ctx);              /* impl/fast_gicp_impl.hpp:50-58 */

@@ -14,7 +14,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
-#include <mutex>
 #include <new>
 
 using namespace pcm;
@@ -52,12 +51,13 @@ struct Workspace {
   std::vector<hipEvent_t> ev_prof;
 };
 
-std::mutex g_ws_mutex;
-Workspace g_ws[16];
-
+// The workspace belongs to the first context of a batch (contexts are single-threaded
+// objects), so independent batches may run concurrently from different host threads
+// on their own streams -- e.g. the stragglers of one batch under the bulk of the next.
 int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, int rounds) {
-  if (c->device < 0 || c->device >= 16) { c->err = "device index out of range"; return PCM_ERR_INVALID_ARGUMENT; }
-  Workspace& w = g_ws[c->device];
+  if (!c->ws) c->ws = new (std::nothrow) Workspace();
+  if (!c->ws) { c->err = "out of host memory"; return PCM_ERR_HIP; }
+  Workspace& w = *static_cast<Workspace*>(c->ws);
   w.device = c->device;
   if (npairs > w.cap_pairs) {
     if (w.d_descs) { hipFree(w.d_descs); hipFree(w.d_states); hipFree(w.d_guesses); hipFree(w.d_results); hipFree(w.d_sums); hipFree(w.d_jobs); }
@@ -95,6 +95,18 @@ int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, i
   return PCM_OK;
 }
 
+void free_ws(pcm_ctx* c) {
+  Workspace* w = static_cast<Workspace*>(c->ws);
+  if (!w) return;
+  hipFree(w->d_descs); hipFree(w->d_states); hipFree(w->d_guesses); hipFree(w->d_results); hipFree(w->d_partials); hipFree(w->d_sums);
+  hipFree(w->d_stats); hipFree(w->d_jobs); hipFree(w->sort.keys); hipFree(w->sort.vals); hipFree(w->sort.tmp);
+  if (w->h_flags) hipHostFree(w->h_flags);
+  for (hipEvent_t e : w->ev_round) hipEventDestroy(e);
+  for (hipEvent_t e : w->ev_prof) hipEventDestroy(e);
+  delete w;
+  c->ws = nullptr;
+}
+
 int coord_mode_for(int model) { return model == PCM_MODEL_P2PLANE ? COORD_ROUND : COORD_FLOOR_HALF; }
 
 int validate_config(pcm_ctx* c, const pcm_config& g) {
@@ -109,11 +121,22 @@ int validate_config(pcm_ctx* c, const pcm_config& g) {
   return PCM_OK;
 }
 
-int set_cloud(pcm_ctx* c, Cloud* cl, const void* points, size_t n, size_t stride, int memory, uint64_t tag) {
+int set_cloud(pcm_ctx* c, Cloud* cl, const void* points, size_t n, size_t stride, int memory, uint64_t tag, bool allow_borrow) {
   if (!points && n) { c->err = "null point buffer"; return PCM_ERR_INVALID_ARGUMENT; }
   if (stride < 3 * sizeof(float) || (stride % sizeof(float)) != 0) { c->err = "stride must be a multiple of 4 and >= 12 bytes"; return PCM_ERR_INVALID_ARGUMENT; }
   if (n > 0x7fffffffull) { c->err = "cloud too large"; return PCM_ERR_INVALID_ARGUMENT; }
   HIPCK(c, hipSetDevice(c->device));
+  if (allow_borrow && memory == PCM_MEM_DEVICE && stride == sizeof(float4) && (reinterpret_cast<uintptr_t>(points) & 15u) == 0) {
+    // a device-resident PointXYZ-layout scan is used in place (the kernels only read x,y,z):
+    // like the reference's shared_ptr input, the caller keeps it alive and unchanged until align() returns
+    cl->drop_buffer();
+    cl->d_pts = const_cast<float4*>(static_cast<const float4*>(points));
+    cl->borrowed = true;
+    cl->n = n;
+    cl->tag = tag;
+    return PCM_OK;
+  }
+  if (cl->borrowed) cl->drop_buffer();
   if (n > cl->cap) {
     if (cl->d_pts) hipFree(cl->d_pts);
     cl->d_pts = nullptr; cl->cap = 0;
@@ -249,7 +272,6 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     if (rc != PCM_OK) { if (c != c0) c0->err = c->err; return rc; }
     max_n = std::max(max_n, c->src.n);
   }
-  std::lock_guard<std::mutex> lock(g_ws_mutex);
   const pcm_config& g = c0->cfg;
   const Geom geom = pick_geom(max_n, n);
   const LsqParams lp = lsq_params(g);
@@ -373,7 +395,6 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
 int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPartialStride]) {
   int rc = prepare(c);
   if (rc != PCM_OK) return rc;
-  std::lock_guard<std::mutex> lock(g_ws_mutex);
   const Geom geom = pick_geom(c->src.n, 1);
   const KernelParams kp = kernel_params(c->cfg, geom);
   Workspace* w = nullptr;
@@ -459,6 +480,7 @@ void pcm_destroy(pcm_ctx* c) {
     c->map.release();
     if (c->planes) hipFree(c->planes);
     if (c->counter) hipFree(c->counter);
+    free_ws(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   }
   delete c;
@@ -498,7 +520,7 @@ int pcm_set_stream(pcm_ctx* c, void* hip_stream) {
 int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes, int memory, uint64_t tag) {
   CHECK_CTX(c);
   if (tag != 0 && tag == c->tgt.tag && c->tgt.n == n) return PCM_OK;  // `if (target_ == cloud) return;`  fast_gicp_impl.hpp:83-85
-  int rc = set_cloud(c, &c->tgt, points, n, stride_bytes, memory, tag);
+  int rc = set_cloud(c, &c->tgt, points, n, stride_bytes, memory, tag, false);
   c->map.valid = false;
   return rc;
 }
@@ -506,7 +528,7 @@ int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
 int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes, int memory, uint64_t tag) {
   CHECK_CTX(c);
   if (tag != 0 && tag == c->src.tag && c->src.n == n) return PCM_OK;  // fast_gicp_impl.hpp:72-74
-  int rc = set_cloud(c, &c->src, points, n, stride_bytes, memory, tag);
+  int rc = set_cloud(c, &c->src, points, n, stride_bytes, memory, tag, true);
   c->src_sorted = false;
   return rc;
 }

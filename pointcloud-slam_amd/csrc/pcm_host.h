@@ -13,13 +13,18 @@
 namespace pcm {
 
 struct Cloud {
-  float4* d_pts = nullptr;  // compact device copy, input order
+  float4* d_pts = nullptr;  // compact float4 points, input order (device copy, or the caller's own device buffer)
   size_t n = 0;
-  size_t cap = 0;
+  size_t cap = 0;           // capacity of an owned buffer
   uint64_t tag = 0;
+  bool borrowed = false;    // d_pts aliases a caller-owned 16-byte-stride device buffer (zero copy)
+  void drop_buffer() {
+    if (d_pts && !borrowed) hipFree(d_pts);
+    d_pts = nullptr; cap = 0; borrowed = false;
+  }
   void release() {
-    if (d_pts) hipFree(d_pts);
-    d_pts = nullptr; n = cap = 0; tag = 0;
+    drop_buffer();
+    n = 0; tag = 0;
   }
 };
 
@@ -96,5 +101,6 @@ struct pcm_ctx {
   std::string err;
   pcm_stats stats{};
   uint64_t phase_cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic (profiling bit2)
+  void* ws = nullptr;   // batch workspace owned by this context (pcm_api.hip)
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };
