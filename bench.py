@@ -103,7 +103,7 @@ def main():
     # ---- inputs (host), before the GPU is touched so that fork() is safe -------------------------
     ncpu = min(len(os.sched_getaffinity(0)), 16 * max(1, world))
     workers = args.gen_workers or max(1, min(ncpu // max(1, min(world, 8)), 16))
-    ids = [rank * args.pairs_per_gpu + i for i in range(args.pairs_per_gpu)]
+    ids = [rank * args.pairs_per_gpu + i for i in range(args.pairs_per_gpu)]   # = sharding.pair_ids_for_rank (kept import-free: runs before the GPU is touched)
     t0 = time.perf_counter()
     pairs = generate_pairs(ids, args.scan_points, args.map_points, workers)
     t_gen = time.perf_counter() - t0
@@ -140,9 +140,9 @@ def main():
 
     # ---- S independent sub-batches per GPU, each driven by its own host thread on its own stream ----
     import threading
-    S = max(1, min(args.pipeline, n_local))
-    bounds = [(n_local * j) // S for j in range(S + 1)]
-    groups = [list(range(bounds[j], bounds[j + 1])) for j in range(S)]
+    from pointcloud_slam_amd import sharding
+    groups = sharding.split_sub_batches(n_local, args.pipeline)
+    S = len(groups)
     pgs = [dist.new_group(list(range(world))) for _ in range(S)] if world > 1 else [None] * S   # one RCCL communicator per pipeline slot
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
@@ -157,10 +157,8 @@ def main():
         res = pcm.align_batch([regs[i] for i in idx], guesses[lo:hi], device_out=d_results.data_ptr() + lo * rec)
         if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per sub-batch)
             with torch.cuda.stream(streams[j]):
-                out = d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec]
-                tmp = torch.empty(world * (hi - lo) * rec, dtype=torch.uint8, device=dev)
-                dist.all_gather_into_tensor(tmp, d_results[lo * rec:hi * rec], group=pgs[j])
-                out.copy_(tmp.view(world, (hi - lo) * rec))
+                got = sharding.gather_records(d_results[lo * rec:hi * rec], world, group=pgs[j])
+                d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got)
             streams[j].synchronize()
         return res
 

@@ -8,5 +8,6 @@ Livox-shaped input generator (``synth.py``) and the batch sharding helper
 library is missing, and contexts fail when no HIP device is present.
 """
 from .capi import PcmError, build_library, library_path, load_library  # noqa: F401
+from . import sharding  # noqa: F401
 from .registration import (P2PlaneRegistration, Registration, RegistrationResult,  # noqa: F401
                            align_batch)

@@ -1,0 +1,78 @@
+"""Sharding of independent (scan, submap) pairs over the GPUs of one node and the
+gather of the solved poses.
+
+The path shards with no data-path collective: every pair is a closed problem
+(SURVEY.md §8e), rank r registers its own contiguous block of pairs, and the only
+exchange is ONE small all-gather of the packed ``pcm_result`` records per batch
+(RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).  The record
+is latency-bound (a few hundred bytes per pair), so it is issued once per batch.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+RECORD_BYTES = ctypes.sizeof(capi.PcmResult)
+
+
+def pair_ids_for_rank(pairs_per_rank: int, rank: int) -> list:
+    """Weak scaling: every rank owns ``pairs_per_rank`` pairs; global ids are contiguous per rank."""
+    return [rank * pairs_per_rank + i for i in range(pairs_per_rank)]
+
+
+def split_sub_batches(n_local: int, n_slots: int) -> list:
+    """Contiguous sub-batches of a rank's pairs (one per pipeline slot / stream)."""
+    n_slots = max(1, min(n_slots, n_local))
+    bounds = [(n_local * j) // n_slots for j in range(n_slots + 1)]
+    return [list(range(bounds[j], bounds[j + 1])) for j in range(n_slots)]
+
+
+def gather_records(local_records, world: int, group=None):
+    """All-gather the packed result records of one (sub-)batch.
+
+    ``local_records``: uint8 tensor of n_local * RECORD_BYTES bytes (device tensor
+    with the nccl/RCCL backend, CPU tensor with gloo).  Returns a (world, n_local *
+    RECORD_BYTES) uint8 tensor on the same device, rank-major.
+    """
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local_records.view(1, -1)
+    out = torch.empty(world * local_records.numel(), dtype=torch.uint8, device=local_records.device)
+    dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)
+    return out.view(world, -1)
+
+
+def records_to_results(raw) -> list:
+    """Decode packed ``pcm_result`` bytes (tensor / bytes / ndarray) into dicts."""
+    if hasattr(raw, "cpu"):
+        raw = raw.cpu().numpy()
+    buf = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8))
+    n = buf.size // RECORD_BYTES
+    arr = (capi.PcmResult * n).from_buffer_copy(buf.tobytes())
+    out = []
+    for r in arr:
+        out.append({"T": np.array(r.T[:], np.float32).reshape(4, 4), "T64": np.array(r.T64[:]).reshape(4, 4),
+                    "iterations": r.iterations, "converged": bool(r.converged), "num_inliers": r.num_inliers,
+                    "num_linearize": r.num_linearize, "status": r.status, "cost": r.cost})
+    return out
+
+
+def pack_results(results) -> np.ndarray:
+    """Inverse of records_to_results for tests: list of dicts -> packed uint8 array."""
+    arr = (capi.PcmResult * len(results))()
+    for r, d in zip(arr, results):
+        T64 = np.asarray(d["T64"], np.float64).reshape(16)
+        for k in range(16):
+            r.T64[k] = T64[k]
+            r.T[k] = np.float32(T64[k])
+        r.iterations = int(d.get("iterations", 0))
+        r.converged = int(d.get("converged", 0))
+        r.num_inliers = int(d.get("num_inliers", 0))
+        r.num_linearize = int(d.get("num_linearize", 0))
+        r.status = int(d.get("status", 0))
+        r.cost = float(d.get("cost", 0.0))
+    return np.frombuffer(bytes(arr), dtype=np.uint8).copy()

@@ -219,3 +219,45 @@ def test_strided_and_device_inputs(pcm, pair10k):
     g3.set_input_target(torch.from_numpy(wide_t).cuda()); g3.set_input_source(torch.from_numpy(p.scan).cuda())
     got = g3.evaluate_cost(p.T_gt)
     assert got[3] == ref[3] and np.array_equal(got[1], ref[1])
+
+
+def test_golden_vectors_gpu(pcm, synth):
+    """The HIP path against the committed golden vectors (tests/golden, made by tests/make_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "p2plane_config1.npz"))
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        c = {k.split("/")[1]: g[k] for k in g.files if k.startswith(name + "/")}
+        p = synth.make_pair(int(c["seed"]), int(c["n_scan"]), int(c["m_map"]))
+        r = _gpu(pcm, str(c["optimizer"]))
+        r.set_input_target(p.submap); r.set_input_source(p.scan)
+        out = r.align(p.guess)
+        dt, dr = pose_error(c["T"], out.T64)
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+        assert out.iterations == int(c["iterations"]) and out.num_inliers == int(c["num_inliers"])
+        # first linearisation of the trace: H, b, cost
+        cost, H, b, inl = r.evaluate_cost(p.guess.astype(np.float64))
+        assert rel_err(H, c["trace"][0, 1:37].reshape(6, 6)) < HB_RTOL and rel_err(b, c["trace"][0, 37:43]) < HB_RTOL
+        assert abs(cost - c["trace"][0, 0]) <= HB_RTOL * c["trace"][0, 0]
+
+
+def test_full_size_properties(pcm, synth):
+    """BASELINE config 2 size (100k-pt scan vs 1M-pt submap), size-independent properties:
+    (1) aligning from the converged pose stays there (idempotence);
+    (2) registering the scan moved by a known rigid motion D gives pose * D^-1 (equivariance);
+    (3) the batch result equals the single result."""
+    p = synth.make_pair(0, 100000, 1000000)
+    g = _gpu(pcm, "GN"); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    r = g.align(p.guess)
+    assert r.converged and r.num_inliers > 0.8 * len(p.scan)
+    r2 = g.align(r.T)
+    dt, dr = pose_error(r.T64, r2.T64)
+    assert r2.iterations <= 2 and dt < 2e-3 and dr < 2e-3
+    D = np.eye(4); D[:3, 3] = [0.05, -0.02, 0.01]
+    moved = p.scan.copy(); moved[:, :3] = p.scan[:, :3] @ D[:3, :3].T + D[:3, 3]
+    g.set_input_source(moved.astype(np.float32))
+    r3 = g.align((p.guess.astype(np.float64) @ np.linalg.inv(D)).astype(np.float32))
+    dt, dr = pose_error(r.T64, r3.T64 @ D)
+    assert dt < 5e-3 and dr < 5e-3
+    g.set_input_source(p.scan)
+    rb = pcm.align_batch([g], p.guess[None])[0]
+    assert np.array_equal(rb.T64, r.T64)
