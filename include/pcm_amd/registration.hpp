@@ -1,0 +1,152 @@
+// include/pcm_amd/registration.hpp -- header-only pcl::Registration adapter over the
+// C ABI of include/pcm_amd.h.
+//
+// Drop-in for the reference's registration operators: same base class
+// (pcl::Registration<PointSource, PointTarget, float>), same setters and call order
+// as fast_gicp::LsqRegistration / FastGICP / FastVGICP
+// (/root/reference/src/pointcloud_match/fast_gicp/include/fast_gicp/gicp/lsq_registration.hpp:15-85,
+//  fast_gicp.hpp:19-100, fast_vgicp.hpp) so that call sites such as
+// jueying_slam/src/localization.cpp:162-189,277,317-340 compile unchanged after
+//     using Registration = pcm_amd::P2PlaneRegistration<pcl::PointXYZ, pcl::PointXYZ>;
+// This header needs PCL + Eigen and therefore only compiles inside a ROS/PCL
+// workspace (neither exists in the build container of this repository); it contains
+// no algorithm, only the translation between PCL/Eigen types and plain pointers.
+#pragma once
+
+#if __has_include(<pcl/registration/registration.h>)
+
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#include <pcl/registration/registration.h>
+
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <iostream>
+#include <stdexcept>
+
+#include "../pcm_amd.h"
+
+namespace pcm_amd {
+
+enum class LSQ_OPTIMIZER_TYPE { GaussNewton, LevenbergMarquardt };   // lsq_registration.hpp:13
+
+template <typename PointSource, typename PointTarget>
+class LsqRegistration : public pcl::Registration<PointSource, PointTarget, float> {
+public:
+  using Scalar = float;
+  using Base = pcl::Registration<PointSource, PointTarget, Scalar>;
+  using Matrix4 = typename Base::Matrix4;
+  using PointCloudSource = typename Base::PointCloudSource;
+  using PointCloudSourceConstPtr = typename PointCloudSource::ConstPtr;
+  using PointCloudTarget = typename Base::PointCloudTarget;
+  using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
+
+protected:
+  using Base::converged_;
+  using Base::final_transformation_;
+  using Base::input_;
+  using Base::max_iterations_;
+  using Base::nr_iterations_;
+  using Base::reg_name_;
+  using Base::target_;
+  using Base::transformation_epsilon_;
+
+public:
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+  explicit LsqRegistration(int model, int device = 0) {
+    reg_name_ = "pcm_amd::LsqRegistration";
+    pcm_default_config(&cfg_);
+    cfg_.model = model;
+    max_iterations_ = cfg_.max_iterations;                 // 64    lsq_registration_impl.hpp:11
+    transformation_epsilon_ = cfg_.translation_eps;        // 5e-4  :13
+    ctx_ = pcm_create(device, &cfg_);
+    if (!ctx_) throw std::runtime_error("pcm_create failed");
+    final_hessian_.setIdentity();                          // :21
+  }
+  ~LsqRegistration() override { pcm_destroy(ctx_); }
+  LsqRegistration(const LsqRegistration&) = delete;
+  LsqRegistration& operator=(const LsqRegistration&) = delete;
+
+  // ---- LsqRegistration surface (lsq_registration_impl.hpp:26-49) ----
+  void setRotationEpsilon(double eps) { cfg_.rotation_eps = eps; }
+  void setInitialLambdaFactor(double f) { cfg_.lm_init_lambda_factor = f; }
+  void setDebugPrint(bool) {}
+  void setOptimizer(LSQ_OPTIMIZER_TYPE t) { cfg_.optimizer = t == LSQ_OPTIMIZER_TYPE::GaussNewton ? PCM_OPT_GAUSS_NEWTON : PCM_OPT_LEVENBERG_MARQUARDT; }
+  const Eigen::Matrix<double, 6, 6>& getFinalHessian() const { return final_hessian_; }
+
+  double evaluateCost(const Eigen::Matrix4f& relative_pose, Eigen::Matrix<double, 6, 6>* H = nullptr, Eigen::Matrix<double, 6, 1>* b = nullptr) {
+    push_config();
+    double T[16], Hr[36], br[6], cost = 0.0;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T[i * 4 + j] = static_cast<double>(relative_pose(i, j));   // Eigen is column-major: transpose into the row-major ABI
+    check(pcm_linearize(ctx_, T, Hr, br, &cost, nullptr), "pcm_linearize");
+    if (H) for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) (*H)(i, j) = Hr[i * 6 + j];
+    if (b) for (int i = 0; i < 6; i++) (*b)(i) = br[i];
+    return cost;
+  }
+
+  // ---- FastGICP surface (fast_gicp_impl.hpp:26-90) ----
+  void setNumThreads(int) {}                                             // no meaning on the GPU
+  void setMaxCorrespondenceDistance(double d) { cfg_.max_range = static_cast<float>(d); cfg_.max_corr_dist = static_cast<float>(d); }
+  void setResolution(double r) { cfg_.voxel_resolution = static_cast<float>(r); }      // fast_vgicp_impl.hpp:28-30
+  void setNumNeighborCells(int n) { cfg_.num_neighbors = n; }            // ivox_nearby_type 0/6/18/26 -> 1/7/19/27
+
+  virtual void swapSourceAndTarget() {
+    input_.swap(target_);
+    check(pcm_swap_source_and_target(ctx_), "pcm_swap_source_and_target");
+  }
+  virtual void clearSource() { input_.reset(); check(pcm_clear_source(ctx_), "pcm_clear_source"); }
+  virtual void clearTarget() { target_.reset(); check(pcm_clear_target(ctx_), "pcm_clear_target"); }
+
+  void setInputSource(const PointCloudSourceConstPtr& cloud) override {
+    if (input_ == cloud) return;                                         // fast_gicp_impl.hpp:72-74
+    Base::setInputSource(cloud);
+    check(pcm_set_source(ctx_, cloud->points.data(), cloud->size(), sizeof(PointSource), PCM_MEM_HOST, reinterpret_cast<uint64_t>(cloud.get())), "pcm_set_source");
+  }
+  void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
+    if (target_ == cloud) return;                                        // :83-85
+    Base::setInputTarget(cloud);
+    check(pcm_set_target(ctx_, cloud->points.data(), cloud->size(), sizeof(PointTarget), PCM_MEM_HOST, reinterpret_cast<uint64_t>(cloud.get())), "pcm_set_target");
+  }
+
+protected:
+  // pcl::Registration::align() calls this (lsq_registration_impl.hpp:52-79)
+  void computeTransformation(PointCloudSource& output, const Matrix4& guess) override {
+    push_config();
+    float g[16];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) g[i * 4 + j] = guess(i, j);
+    pcm_result r;
+    const int rc = pcm_align(ctx_, g, &r);
+    if (rc == PCM_ERR_NOT_CONVERGED) std::cerr << "lm not converged!!" << std::endl;      // :70
+    else check(rc, "pcm_align");
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) final_transformation_(i, j) = r.T[i * 4 + j];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) final_hessian_(i, j) = r.H[i * 6 + j];
+    nr_iterations_ = r.iterations;
+    converged_ = r.converged != 0;
+    pcl::transformPointCloud(*input_, output, final_transformation_);                    // :78
+  }
+
+  void push_config() {
+    cfg_.max_iterations = max_iterations_;                   // setMaximumIterations
+    cfg_.translation_eps = transformation_epsilon_;          // setTransformationEpsilon
+    check(pcm_set_config(ctx_, &cfg_), "pcm_set_config");
+  }
+  void check(int rc, const char* what) const {
+    if (rc != PCM_OK) throw std::runtime_error(std::string(what) + ": " + pcm_last_error(ctx_));
+  }
+
+  pcm_ctx* ctx_ = nullptr;
+  pcm_config cfg_;
+  Eigen::Matrix<double, 6, 6> final_hessian_;
+};
+
+// point-to-plane scan-to-submap ICP with jueying_lio's matcher semantics
+template <typename PointSource, typename PointTarget>
+class P2PlaneRegistration : public LsqRegistration<PointSource, PointTarget> {
+public:
+  explicit P2PlaneRegistration(int device = 0) : LsqRegistration<PointSource, PointTarget>(PCM_MODEL_P2PLANE, device) { this->reg_name_ = "pcm_amd::P2PlaneRegistration"; }
+};
+
+}  // namespace pcm_amd
+
+#endif  // __has_include(<pcl/registration/registration.h>)
