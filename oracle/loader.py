@@ -64,6 +64,7 @@ def lib():
         L.orc_test_esti_plane.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.orc_test_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_test_voxel_key.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_test_gauss_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _LIB = L
     return _LIB
 

@@ -80,6 +80,7 @@ void orc_test_ldlt6_solve(const double A[36], const double b[6], double x[6]);
 int orc_test_esti_plane(const float *pts_xyz, int n, float threshold, float plane[4]);
 int orc_test_knn(void *h, const float q[3], int *idx_out, float *d2_out);
 long orc_test_voxel_key(void *h, const float p[3], int key[3]);
+int orc_test_gauss_voxel(void *h, const float p[3], float mean[3], float cov[9], int *n);
 
 #ifdef __cplusplus
 }

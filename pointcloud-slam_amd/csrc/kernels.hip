@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restric
     __shared__ double s_grp[32 * kPartialStride];
     __shared__ double s_tot[kPartialStride];
     const PairDesc d = descs[pair];
-    const uint32_t per = trial_round ? (uint32_t)kp.points_per_block : 256u;
+    const uint32_t per = (uint32_t)(trial_round ? kp.points_per_block : kp.lin_points_per_block);
     const int nblocks = (int)((d.src.num_points + per - 1u) / per);
     const int j = threadIdx.x & 31, r = threadIdx.x >> 5;
     double v = 0.0;
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
 
   if (use_lds) {
     const int ox0 = s_box[0], oy0 = s_box[1], oz0 = s_box[2];
-    const int Dx = s_box[3], Dy = s_box[4], Dz = s_box[5], ncell = s_box[6];
+    const int Dx = s_box[3], Dy = s_box[4], Dz = s_box[5];
     const int bx0 = s_bbox[0], by0 = s_bbox[1], bz0 = s_bbox[2], nby = s_bbox[4], nbz = s_bbox[5], nb = s_bbox[6];
     // ---- one probe per BRICK under the box (wave 0), exclusive scan of their point counts -------
     if (wave == 0) {

@@ -109,8 +109,13 @@ void free_ws(pcm_ctx* c) {
 
 int coord_mode_for(int model) { return model == PCM_MODEL_P2PLANE ? COORD_ROUND : COORD_FLOOR_HALF; }
 
+size_t num_elements(const pcm_ctx* c) { return c->cfg.model == PCM_MODEL_NDT_D2D ? (size_t)c->srcmap.num_voxels : c->src.n; }
+
+bool is_ndt(int model) { return model == PCM_MODEL_NDT_P2D || model == PCM_MODEL_NDT_D2D; }
+
 int validate_config(pcm_ctx* c, const pcm_config& g) {
-  if (g.model != PCM_MODEL_P2PLANE) { c->err = "model not built in this library revision"; return PCM_ERR_UNSUPPORTED; }
+  if (g.model != PCM_MODEL_P2PLANE && !is_ndt(g.model)) { c->err = "model not built in this library revision (P2PLANE, NDT_P2D, NDT_D2D are)"; return PCM_ERR_UNSUPPORTED; }
+  if (is_ndt(g.model) && g.num_neighbors == 19) { c->err = "NDT neighbourhoods are DIRECT1 / DIRECT7 / DIRECT27 (num_neighbors 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT; }
   if (g.optimizer != PCM_OPT_GAUSS_NEWTON && g.optimizer != PCM_OPT_LEVENBERG_MARQUARDT) { c->err = "bad optimizer"; return PCM_ERR_INVALID_ARGUMENT; }
   if (!(g.voxel_resolution > 0.f)) { c->err = "voxel_resolution must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
   if (g.num_neighbors != 1 && g.num_neighbors != 7 && g.num_neighbors != 19 && g.num_neighbors != 27) {
@@ -156,11 +161,26 @@ int prepare(pcm_ctx* c) {
   if (c->src.n == 0 || c->tgt.n == 0) { c->err = "align before setInputSource/setInputTarget"; return PCM_ERR_NO_INPUT; }
   HIPCK(c, hipSetDevice(c->device));
   const int mode = coord_mode_for(c->cfg.model);
-  if (!c->map.valid || c->map.res != c->cfg.voxel_resolution || c->map.coord_mode != mode) {
-    int rc = build_target_map(c->stream, c->tgt.d_pts, (uint32_t)c->tgt.n, c->cfg.voxel_resolution, mode, &c->map, &c->err);
+  const bool gauss = is_ndt(c->cfg.model);
+  if (!c->map.valid || c->map.res != c->cfg.voxel_resolution || c->map.coord_mode != mode || (gauss && !c->map.gvox)) {
+    int rc = build_target_map(c->stream, c->tgt.d_pts, (uint32_t)c->tgt.n, c->cfg.voxel_resolution, mode, gauss, &c->map, &c->err);
     if (rc != PCM_OK) return rc;
     c->stats.target_voxels = c->map.num_voxels;
     c->stats.target_slots = c->map.cap;
+  }
+  if (c->cfg.model == PCM_MODEL_NDT_D2D && (!c->srcmap.valid || c->srcmap.res != c->cfg.voxel_resolution)) {
+    // D2D: the source elements are the source-voxel distributions (ndt_cuda.cu:120-129,156-158)
+    int rc = build_target_map(c->stream, c->src.d_pts, (uint32_t)c->src.n, c->cfg.voxel_resolution, mode, true, &c->srcmap, &c->err);
+    if (rc != PCM_OK) return rc;
+  }
+  if (gauss) {
+    const size_t need = num_elements(c) * (size_t)c->cfg.num_neighbors;
+    if (c->corr_cap < need) {
+      if (c->corr) hipFree(c->corr);
+      c->corr = nullptr; c->corr_cap = 0;
+      HIPCK(c, hipMalloc(&c->corr, sizeof(int32_t) * need));
+      c->corr_cap = need;
+    }
   }
   if (c->cfg.sort_source && c->src_order_cap < c->src.n) {
     if (c->src_order) hipFree(c->src_order);
@@ -188,7 +208,7 @@ struct Geom {
   int tiles_per_pair;    // correspondence-search kernel (256-point tiles)
 };
 
-Geom pick_geom(size_t max_n, int npairs) {
+Geom pick_geom(size_t max_n, int npairs, bool ndt = false) {
   // residual kernel: streaming 32 B/point; each lane amortises the 29-value wave
   // reduction over several points, but keep >= ~1024 workgroups in flight
   size_t total = max_n * (size_t)npairs;
@@ -197,7 +217,7 @@ Geom pick_geom(size_t max_n, int npairs) {
   Geom g;
   g.points_per_block = (int)ppb;
   g.blocks_per_pair = (int)((max_n + ppb - 1) / ppb);
-  g.tiles_per_pair = (int)((max_n + 255) / 256);
+  g.tiles_per_pair = ndt ? g.blocks_per_pair : (int)((max_n + 255) / 256);   // NDT linearize uses the streaming geometry
   return g;
 }
 
@@ -211,8 +231,11 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->tgt.num_points = c->map.num_points;
   d->tgt.inv_res = c->map.inv_res;
   d->tgt.res = c->map.res;
+  d->tgt.gvox = c->map.gvox;
   d->src.pts = (c->cfg.sort_source && c->src_sorted) ? c->src_order : c->src.d_pts;
-  d->src.num_points = (uint32_t)c->src.n;
+  d->src.gvox = c->srcmap.gvox;
+  d->src.num_points = (uint32_t)num_elements(c);
+  d->corr = c->corr;
   d->planes = c->planes;
   d->partials = partials;
   d->counter = c->counter;
@@ -235,6 +258,7 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.tiles_per_pair = geom.tiles_per_pair;
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
   kp.do_step = 1;
+  kp.lin_points_per_block = is_ndt(g.model) ? geom.points_per_block : 256;
   return kp;
 }
 
@@ -252,7 +276,8 @@ LsqParams lsq_params(const pcm_config& g) {
 bool same_solver_config(const pcm_config& a, const pcm_config& b) {
   return a.model == b.model && a.optimizer == b.optimizer && a.max_iterations == b.max_iterations && a.lm_max_iterations == b.lm_max_iterations &&
          a.rotation_eps == b.rotation_eps && a.translation_eps == b.translation_eps && a.lm_init_lambda_factor == b.lm_init_lambda_factor &&
-         a.num_neighbors == b.num_neighbors && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold && a.flags == b.flags;
+         a.num_neighbors == b.num_neighbors && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold && a.flags == b.flags &&
+         (a.model == PCM_MODEL_P2PLANE || a.voxel_resolution == b.voxel_resolution);
 }
 
 int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_result* host_out, void* device_out) {
@@ -270,10 +295,11 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     }
     int rc = prepare(c);
     if (rc != PCM_OK) { if (c != c0) c0->err = c->err; return rc; }
-    max_n = std::max(max_n, c->src.n);
+    max_n = std::max(max_n, num_elements(c));
   }
   const pcm_config& g = c0->cfg;
-  const Geom geom = pick_geom(max_n, n);
+  const bool ndt = is_ndt(g.model);
+  const Geom geom = pick_geom(max_n, n, ndt);
   const LsqParams lp = lsq_params(g);
   const KernelParams kp = kernel_params(g, geom);
   // worst case: every outer iteration = 1 linearize + lm_max_iterations trials
@@ -290,7 +316,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     uint32_t total = 0, jmax = 0;
     for (int i = 0; i < n; i++) {
       pcm_ctx* c = ctxs[i];
-      if (!c->cfg.sort_source || c->src_sorted) continue;
+      if (!c->cfg.sort_source || c->src_sorted || c->cfg.model == PCM_MODEL_NDT_D2D) continue;
       SortJob j{c->src.d_pts, c->src_order, (uint32_t)c->src.n, total, (uint32_t)i, 0};
       jobs.push_back(j);
       total += j.n;
@@ -324,11 +350,13 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     }
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
-    launch_linearize(st, w->d_descs, w->d_states, kp, n, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
+    if (ndt) launch_ndt(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_NDT_D2D, false);
+    else launch_linearize(st, w->d_descs, w->d_states, kp, n, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
     launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums);
     if (is_lm) {
-      launch_trial(st, w->d_descs, w->d_states, kp, n);
+      if (ndt) launch_ndt(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_NDT_D2D, true);
+      else launch_trial(st, w->d_descs, w->d_states, kp, n);
       launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, true, true, w->d_flags + (size_t)r * n, w->d_sums);
     }
     if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st)); prof_used += 3; }
@@ -383,7 +411,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   uint64_t passes = 0;
   int worst = PCM_OK;
   for (int i = 0; i < n; i++) {
-    passes += (uint64_t)(h_res[i].num_linearize + h_res[i].num_compute_error) * ctxs[i]->src.n;
+    passes += (uint64_t)(h_res[i].num_linearize + h_res[i].num_compute_error) * num_elements(ctxs[i]);
     if (h_res[i].status != PCM_OK) worst = h_res[i].status;
   }
   c0->stats.point_passes += passes;
@@ -395,7 +423,8 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
 int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPartialStride]) {
   int rc = prepare(c);
   if (rc != PCM_OK) return rc;
-  const Geom geom = pick_geom(c->src.n, 1);
+  const bool ndt = is_ndt(c->cfg.model);
+  const Geom geom = pick_geom(num_elements(c), 1, ndt);
   const KernelParams kp = kernel_params(c->cfg, geom);
   Workspace* w = nullptr;
   rc = ensure_ws(c, &w, 1, (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride, 2);
@@ -411,7 +440,8 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   HIPCK(c, hipMemcpyAsync(w->d_states, &s, sizeof(s), hipMemcpyHostToDevice, c->stream));
   KernelParams kp1 = kp;
   kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
-  if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
+  if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_NDT_D2D, !linearize);
+  else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
   launch_finish_round(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, !linearize, false, w->d_flags, w->d_sums);
   HIPCK(c, hipGetLastError());
@@ -478,6 +508,8 @@ void pcm_destroy(pcm_ctx* c) {
     c->tgt.release();
     if (c->src_order) hipFree(c->src_order);
     c->map.release();
+    c->srcmap.release();
+    if (c->corr) hipFree(c->corr);
     if (c->planes) hipFree(c->planes);
     if (c->counter) hipFree(c->counter);
     free_ws(c);
@@ -530,6 +562,7 @@ int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   if (tag != 0 && tag == c->src.tag && c->src.n == n) return PCM_OK;  // fast_gicp_impl.hpp:72-74
   int rc = set_cloud(c, &c->src, points, n, stride_bytes, memory, tag, true);
   c->src_sorted = false;
+  c->srcmap.valid = false;
   return rc;
 }
 
@@ -538,13 +571,14 @@ int pcm_swap_source_and_target(pcm_ctx* c) {
   HIPCK(c, hipStreamSynchronize(c->stream));
   std::swap(c->src, c->tgt);
   c->map.valid = false;
+  c->srcmap.valid = false;
   c->src_sorted = false;
   return PCM_OK;
 }
 
 int pcm_clear_source(pcm_ctx* c) {
   CHECK_CTX(c);
-  c->src.n = 0; c->src.tag = 0; c->src_sorted = false;
+  c->src.n = 0; c->src.tag = 0; c->src_sorted = false; c->srcmap.valid = false;
   return PCM_OK;
 }
 

@@ -60,6 +60,17 @@ __host__ __device__ inline uint32_t hash_coord(int x, int y, int z) {
   return hash_finish((uint32_t)x * 0x9E3779B1u + (uint32_t)y * 0x85EBCA77u + (uint32_t)z * 0xC2B2AE3Du);
 }
 
+// Gaussian voxel payload of the NDT / VGICP models: one 48-byte record per occupied voxel,
+// same order as vox_start (reference layout: int + Vector3f + Matrix3f = 52 B,
+// fast_gicp/include/fast_gicp/cuda/gaussian_voxelmap.cuh:36-38)
+struct GaussVoxel {
+  float mx, my, mz;
+  int32_t n;
+  float c00, c01, c02, c11, c12, c22;   // regularised covariance (symmetric)
+  float pad0, pad1;
+};
+static_assert(sizeof(GaussVoxel) == 48, "GaussVoxel must be 48 bytes");
+
 // voxel-coordinate conventions of the reference
 enum CoordMode : int32_t {
   COORD_ROUND = 0,       // iVox Pos2Grid: round(p * inv_res)          jueying_lio/include/ivox3d/ivox3d.h:283-286
@@ -101,6 +112,7 @@ struct TargetView {
   const BrickSlot* bricks;
   const uint32_t* bmask;
   const uint16_t* bpref;
+  const GaussVoxel* gvox;   // NDT / VGICP models only
   uint32_t mask;       // brick-table capacity - 1
   uint32_t num_points;
   float inv_res;       // float(1.0 / res)
@@ -108,8 +120,9 @@ struct TargetView {
 };
 
 struct SourceView {
-  const float4* pts;
-  uint32_t num_points;
+  const float4* pts;         // scan points (P2PLANE, NDT P2D)
+  const GaussVoxel* gvox;    // source voxel distributions (NDT D2D: the elements are these)
+  uint32_t num_points;       // number of source elements
 };
 
 // per-pair descriptor read by the residual kernels
@@ -117,6 +130,7 @@ struct PairDesc {
   TargetView tgt;
   SourceView src;
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
+  int32_t* corr;        // NDT: [elements][offsets] matched target voxel (or -1) of the last linearize
   double* partials;     // [workgroups of the round][kPartialStride]
   unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)
 };
@@ -134,7 +148,8 @@ struct KernelParams {
   int32_t points_per_block;   // k_trial points per workgroup
   int32_t tiles_per_pair;     // k_linearize grid.x (256-point tiles)
   int32_t use_lds;            // 0: always probe the global table per lane (A/B and parity checks)
-  int32_t do_step;            // 1: the last workgroup runs the GN/LM step; 0: it exports the sums (parity hooks)
+  int32_t do_step;            // 1: k_finish_round runs the GN/LM step; 0: it exports the sums (parity hooks)
+  int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)
 };
 
 }  // namespace pcm

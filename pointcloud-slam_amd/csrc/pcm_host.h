@@ -34,6 +34,7 @@ struct TargetMap {   // layout: pcm_device.h
   uint16_t* bpref = nullptr;
   uint32_t* vox_start = nullptr;
   float4* pts = nullptr;
+  GaussVoxel* gvox = nullptr;   // NDT / VGICP models
   uint32_t cap = 0, num_voxels = 0, num_bricks = 0, num_points = 0;
   float res = 0.f, inv_res = 0.f;
   int coord_mode = 0;
@@ -44,12 +45,14 @@ struct TargetMap {   // layout: pcm_device.h
     if (bpref) hipFree(bpref);
     if (vox_start) hipFree(vox_start);
     if (pts) hipFree(pts);
+    if (gvox) hipFree(gvox);
+    gvox = nullptr;
     bricks = nullptr; bmask = nullptr; bpref = nullptr; vox_start = nullptr; pts = nullptr;
     cap = num_voxels = num_bricks = num_points = 0; valid = false;
   }
 };
 
-int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, TargetMap* map, std::string* err);
+int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, bool want_gauss, TargetMap* map, std::string* err);
 int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, float4* d_out, std::string* err);
 // batched scan re-ordering (voxel_hash.hip)
 struct SortJob {
@@ -80,6 +83,7 @@ void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairSta
 void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs);
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
                          bool write_flags, unsigned char* d_flags_row, double* d_sums);
+void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool d2d, bool trial);
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
 
@@ -92,6 +96,9 @@ struct pcm_ctx {
   bool own_stream = false;
   pcm::Cloud src, tgt;
   pcm::TargetMap map;
+  pcm::TargetMap srcmap;          // NDT D2D: the source's own voxel distributions
+  int32_t* corr = nullptr;        // NDT: matched voxel per (element, offset) of the last linearize
+  size_t corr_cap = 0;
   float4* src_order = nullptr;   // the scan re-ordered along the world-grid Morton curve (speed only)
   size_t src_order_cap = 0;
   bool src_sorted = false;       // src_order holds the current source

@@ -138,8 +138,117 @@ __global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* _
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// ---------------------------------------------------------------------------
+// Gaussian voxel statistics of the NDT models:
+//   sums .......... gaussian_voxelmap.cu:122-148 (x and x x^T per voxel)
+//   mean / cov .... gaussian_voxelmap.cu:178-198  cov = (sum x x^T - mean * sum x^T) / n
+//   MIN_EIG ....... covariance_regularization.cu:83-97  eigenvalues clamped to >= 1e-3
+// The reference adds the 13 numbers of every point with float atomics (run-to-run
+// order dependent); here a voxel's points are one contiguous run in input order and
+// one lane sums them in double -- deterministic, no atomics.
+// ---------------------------------------------------------------------------
+__device__ inline void eig3_sym_jacobi(const double (&Ain)[9], double (&w)[3], double (&V)[9]) {
+  double A[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 64; sweep++) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-32 * diag || off == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+      for (int q = p + 1; q < 3; q++) {
+        const double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+          V[k * 3 + p] = c * vkp - s * vkq;
+          V[k * 3 + q] = s * vkp + c * vkq;
+        }
+      }
+    }
+  }
+  w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (j < 2 - i && w[j] > w[j + 1]) {
+        const double t = w[j]; w[j] = w[j + 1]; w[j + 1] = t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const double u = V[k * 3 + j]; V[k * 3 + j] = V[k * 3 + j + 1]; V[k * 3 + j + 1] = u; }
+      }
+    }
+  }
+}
+
+__global__ void k_gauss_voxels(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, uint32_t nvox, GaussVoxel* __restrict__ out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t p0 = vox_start[v], p1 = vox_start[v + 1];
+  double sx[3] = {0.0, 0.0, 0.0}, sxx[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (uint32_t k = p0; k < p1; k++) {
+    const float4 p = pts[k];
+    const float x[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      sx[a] += (double)x[a];
+#pragma unroll
+      for (int b = 0; b < 3; b++) sxx[a * 3 + b] += (double)(x[a] * x[b]);   // the product is a float, as in the reference
+    }
+  }
+  const double nn = (double)(p1 - p0);
+  double mean[3], cov[9];
+#pragma unroll
+  for (int a = 0; a < 3; a++) mean[a] = sx[a] / nn;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) cov[a * 3 + b] = (sxx[a * 3 + b] - mean[a] * sx[b]) / nn;
+  }
+  cov[1] = cov[3]; cov[2] = cov[6]; cov[5] = cov[7];   // self-adjoint: lower triangle
+  double w[3], V[9];
+  eig3_sym_jacobi(cov, w, V);
+#pragma unroll
+  for (int k = 0; k < 3; k++) w[k] = w[k] > 1e-3 ? w[k] : 1e-3;
+  float c[9];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) s += V[a * 3 + k] * w[k] * V[b * 3 + k];
+      c[a * 3 + b] = (float)s;
+    }
+  }
+  GaussVoxel g;
+  g.mx = (float)mean[0]; g.my = (float)mean[1]; g.mz = (float)mean[2];
+  g.n = (int32_t)(p1 - p0);
+  g.c00 = c[0]; g.c01 = c[1]; g.c02 = c[2]; g.c11 = c[4]; g.c12 = c[5]; g.c22 = c[8];
+  g.pad0 = 0.f; g.pad1 = 0.f;
+  out[v] = g;
+}
+
 // Build the voxel hash of `cloud` into `map`.  One host sync (voxel / brick counts -> array sizes).
-int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, TargetMap* map, std::string* err) {
+int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, bool want_gauss, TargetMap* map, std::string* err) {
   map->release();
   if (n == 0) { *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
   uint64_t *keys = nullptr, *keys_s = nullptr;
@@ -201,6 +310,11 @@ int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float 
     CK(hipGetLastError());
     k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, keys_s, n, map->bricks, cap - 1, map->pts);
     CK(hipGetLastError());
+    if (want_gauss) {
+      CK(hipMalloc(&map->gvox, sizeof(GaussVoxel) * ((size_t)nvox + 1)));
+      k_gauss_voxels<<<cdiv(nvox, 128), 128, 0, stream>>>(map->pts, map->vox_start, nvox, map->gvox);
+      CK(hipGetLastError());
+    }
     CK(hipStreamSynchronize(stream));
     map->cap = cap;
     map->num_voxels = nvox;

@@ -55,12 +55,17 @@ class Registration:
     """One registration object bound to a HIP device (= one ``pcm_ctx``)."""
 
     model = "P2PLANE"
+    defaults = {}
 
-    def __init__(self, device: int = 0, **params):
+    def __init__(self, device: int = 0, model: str = None, **params):
         self._L = capi.load_library()
         cfg = capi.PcmConfig()
         self._L.pcm_default_config(C.byref(cfg))
+        if model is not None:
+            self.model = model
         cfg.model = capi.MODEL[self.model]
+        for k, v in self.defaults.items():
+            setattr(cfg, k, v)
         self._cfg = cfg
         self._h = self._L.pcm_create(device, C.byref(cfg))
         if not self._h:
@@ -172,6 +177,17 @@ class P2PlaneRegistration(Registration):
     (5-NN in the voxel hash -> plane fit -> n.p+d; laser_mapping.cc:592-701)
     under fast_gicp's GN/LM loop."""
     model = "P2PLANE"
+
+
+class NdtRegistration(Registration):
+    """NDT on Gaussian voxels with the reference NDTCuda's semantics
+    (fast_gicp/include/fast_gicp/ndt/ndt_cuda.hpp:21-71, src/fast_gicp/cuda/ndt_cuda.cu):
+    D2D distance mode, DIRECT7 neighbourhood and resolution 1.0 by default (ndt_cuda.cu:15-22)."""
+    model = "NDT_D2D"
+    defaults = {"voxel_resolution": 1.0, "num_neighbors": 7}
+
+    def set_distance_mode(self, mode: str):      # setDistanceMode(NDTDistanceMode)
+        self._set(model=capi.MODEL["NDT_" + mode.upper()])
 
 
 def align_batch(regs, guesses, device_out=None):

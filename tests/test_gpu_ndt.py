@@ -1,0 +1,64 @@
+"""GPU parity of the NDT models (P2D / D2D on Gaussian voxels) against the oracle."""
+import numpy as np
+import pytest
+
+from helpers import HB_RTOL, POSE_TOL_M, POSE_TOL_RAD, pose_error, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair_dense(synth):
+    # NDT voxels need > 6 points (ndt_compute_derivatives.cu:61): a denser submap than the LIO-like default
+    return synth.make_pair(0, 10000, 100000, density=60.0)
+
+
+def _both(pcm, model, nn, optimizer, p, res=1.0):
+    from oracle import Oracle
+    o = Oracle(model, optimizer, voxel_resolution=res, num_neighbors=nn)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g = pcm.NdtRegistration(0, model=model, optimizer=optimizer, voxel_resolution=res, num_neighbors=nn)
+    g.set_input_target(p.submap); g.set_input_source(p.scan)
+    return o, g
+
+
+@pytest.mark.parametrize("model", ["NDT_P2D", "NDT_D2D"])
+@pytest.mark.parametrize("nn", [1, 7, 27])
+def test_ndt_linearize_matches_oracle(pcm, pair_dense, model, nn):
+    p = pair_dense
+    o, g = _both(pcm, model, nn, "LM", p)
+    for T in (p.guess.astype(np.float64), p.T_gt):
+        c0, H0, b0 = o.linearize(T)
+        c1, H1, b1, inl = g.evaluate_cost(T)
+        assert inl == o.num_inliers and inl > 0
+        assert rel_err(H1, H0) < HB_RTOL and rel_err(b1, b0) < HB_RTOL and abs(c1 - c0) <= HB_RTOL * abs(c0)
+        T2 = T.copy(); T2[:3, 3] += [0.02, -0.01, 0.01]     # trial pose on the remembered correspondences
+        assert abs(g.compute_error(T2) - o.compute_error(T2)) <= HB_RTOL * abs(o.compute_error(T2))
+
+
+@pytest.mark.parametrize("model,nn,optimizer", [("NDT_P2D", 1, "LM"), ("NDT_D2D", 7, "LM"), ("NDT_D2D", 1, "GN"), ("NDT_P2D", 7, "GN")])
+def test_ndt_align_matches_oracle(pcm, pair_dense, model, nn, optimizer):
+    from oracle.loader import result_T
+    p = pair_dense
+    o, g = _both(pcm, model, nn, optimizer, p)
+    ro, rg = o.align(p.guess), g.align(p.guess)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+    assert rg.iterations == ro.iterations and rg.converged == bool(ro.converged)
+    assert rg.num_linearize == ro.num_linearize and rg.num_compute_error == ro.num_compute_error
+
+
+def test_ndt_batch_and_swap(pcm, synth):
+    pairs = [synth.make_pair(20 + i, 3000 + 1000 * i, 30000 + 8000 * i, density=60.0) for i in range(3)]
+    regs = []
+    for p in pairs:
+        g = pcm.NdtRegistration(0); g.set_input_target(p.submap); g.set_input_source(p.scan); regs.append(g)
+    singles = [g.align(p.guess) for g, p in zip(regs, pairs)]
+    batch = pcm.align_batch(regs, np.stack([p.guess for p in pairs]))
+    for s, b in zip(singles, batch):
+        assert np.array_equal(s.T64, b.T64)
+    # swapSourceAndTarget (ndt_cuda.cu:90-93) then setting both again == fresh object
+    p = pairs[0]
+    g = pcm.NdtRegistration(0); g.set_input_target(p.scan); g.set_input_source(p.submap)
+    g.swap_source_and_target()
+    assert np.array_equal(g.align(p.guess).T64, singles[0].T64)
