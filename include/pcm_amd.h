@@ -170,6 +170,32 @@ int pcm_compute_error(pcm_ctx *ctx, const double T[16], double *cost);
  * holds 4*n floats. */
 int pcm_get_planes(pcm_ctx *ctx, float *out, size_t n);
 
+/* jueying_lio measurement model: the h_dyn_share callback LaserMapping::ObsModel
+ * (jueying_lio/src/laser_mapping.cc:592-701) together with the reduction the IEKF applies
+ * to its output, HTH = h_x^T h_x (12x12) and h_x^T h (esekfom.hpp:1687,1706).
+ * State = the pose part of state_ikfom; quaternions in Eigen coefficient order (x,y,z,w).
+ * rematch = ekfom_data.converge: non-zero -> 5-NN + plane fit for every scan point;
+ * zero -> the planes of the previous call are re-used (laser_mapping.cc:616).
+ * Target = the map (pcm_set_target), source = the down-sampled scan in the LiDAR frame.
+ * One documented difference: a point failing the ||p|| > 81 pd2^2 test is dropped for
+ * this call (the reference keeps a stale residual, laser_mapping.cc:632-635). */
+typedef struct pcm_lio_state {
+  double rot[4];     /* s.rot            world <- imu */
+  double pos[3];     /* s.pos */
+  double off_R[4];   /* s.offset_R_L_I   imu <- lidar */
+  double off_T[3];   /* s.offset_T_L_I */
+} pcm_lio_state;
+
+typedef struct pcm_obs_result {
+  double HTH[144];   /* row-major 12x12 */
+  double HTh[12];
+  double sum_h2;     /* sum of squared residuals */
+  int32_t n_eff;     /* effect_feat_num_ */
+  int32_t valid;     /* ekfom_data.valid (0 when n_eff < 1, laser_mapping.cc:657-661) */
+} pcm_obs_result;
+
+int pcm_obs_model(pcm_ctx *ctx, const pcm_lio_state *state, int extrinsic_est_en, int rematch, pcm_obs_result *out);
+
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel
  * launches, no host round trip per iteration.  `guesses` = n x 16 floats.

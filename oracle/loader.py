@@ -25,6 +25,10 @@ class OracleConfig(C.Structure):
                 ("regularization", C.c_int), ("num_threads", C.c_int)]
 
 
+class LioState(C.Structure):
+    _fields_ = [("rot", C.c_double * 4), ("pos", C.c_double * 3), ("off_R", C.c_double * 4), ("off_T", C.c_double * 3)]
+
+
 class OracleResult(C.Structure):
     _fields_ = [("T", C.c_float * 16), ("T64", C.c_double * 16), ("H", C.c_double * 36),
                 ("cost", C.c_double), ("iterations", C.c_int), ("converged", C.c_int),
@@ -56,6 +60,7 @@ def lib():
         L.orc_compute_error.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_num_inliers.argtypes = [C.c_void_p]
         L.orc_get_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+        L.orc_obs_model.argtypes = [C.c_void_p, C.POINTER(LioState), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OracleResult)]
         L.orc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace_count.argtypes = [C.c_void_p]
@@ -130,6 +135,14 @@ class Oracle:
         if lib().orc_get_planes(self._h, pl.ctypes.data, sel.ctypes.data, n) != 0:
             raise RuntimeError("orc_get_planes")
         return pl, sel.astype(bool)
+
+    def obs_model(self, rot_xyzw, pos, off_R_xyzw, off_T, extrinsic_est_en=False, converge=True):
+        """ObsModel + IEKF reduction -> (HTH 12x12, HTh 12, n_eff, sum_h2); n_eff == 0 <=> not valid."""
+        st = LioState()
+        st.rot[:] = list(rot_xyzw); st.pos[:] = list(pos); st.off_R[:] = list(off_R_xyzw); st.off_T[:] = list(off_T)
+        HTH = np.zeros((12, 12)); HTh = np.zeros(12); n = C.c_int(); s2 = C.c_double()
+        lib().orc_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), HTH.ctypes.data, HTh.ctypes.data, C.byref(n), C.byref(s2))
+        return HTH, HTh, n.value, s2.value
 
     def enable_trace(self, max_records=256):
         self._trace = np.zeros((max_records, 43))

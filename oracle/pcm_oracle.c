@@ -410,6 +410,112 @@ static double p2plane_compute_error(oracle *o, const double T[16]) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* jueying_lio ObsModel + IEKF reduction                                       */
+/* ------------------------------------------------------------------------- */
+/* Eigen::Quaternion product a * b, coefficients (x, y, z, w) */
+static void quat_mul(const double a[4], const double b[4], double r[4]) {
+  r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+/* Eigen QuaternionBase::_transformVector: uv = u x v; uv += uv; v + w*uv + u x uv */
+#define ORC_DEF_QROT(NAME, T)                                                     \
+  static void NAME(const T q[4], const T v[3], T r[3]) {                          \
+    T uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]}; \
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];                               \
+    const T c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]}; \
+    for (int a = 0; a < 3; a++) r[a] = v[a] + q[3] * uv[a] + c[a];                \
+  }
+ORC_DEF_QROT(quat_rot_d, double)
+ORC_DEF_QROT(quat_rot_f, float)
+/* Eigen Quaternion::toRotationMatrix, coefficients (x, y, z, w) -> row-major 3x3 */
+static void quat_to_rot_xyzw(const double q[4], double R[9]) {
+  const double w[4] = {q[3], q[0], q[1], q[2]};
+  orc_quat_to_rot(w, R);
+}
+
+int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int converge, double HTH[144], double HTh[12], int *n_eff, double *sum_h2) {
+  oracle *o = (oracle *)h;
+  p2plane_prepare(o);
+  /* R_wl = (s.rot * s.offset_R_L_I).cast<float>() ; t_wl = (s.rot * s.offset_T_L_I + s.pos).cast<float>()   :602-603 */
+  double qwl[4], twl[3];
+  quat_mul(s->rot, s->off_R, qwl);
+  quat_rot_d(s->rot, s->off_T, twl);
+  float qf[4], tf[3];
+  for (int a = 0; a < 4; a++) qf[a] = (float)qwl[a];
+  for (int a = 0; a < 3; a++) tf[a] = (float)(twl[a] + s->pos[a]);
+  /* off_R, off_t, Rt as float matrices   :669-671 */
+  double Rd[9], ORd[9];
+  quat_to_rot_xyzw(s->rot, Rd);
+  quat_to_rot_xyzw(s->off_R, ORd);
+  float Rt[9], offR[9], offt[3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rt[i * 3 + j] = (float)Rd[j * 3 + i]; offR[i * 3 + j] = (float)ORd[i * 3 + j]; }
+  for (int a = 0; a < 3; a++) offt[a] = (float)s->off_T[a];
+  const long n = o->src.n;
+  const int K = o->cfg.knn;
+  double acc[92];
+  memset(acc, 0, sizeof(acc));
+  orc_distpt_buf buf = {0, 0};
+  int idx[ORC_QR_MAXR];
+  float near[ORC_QR_MAXR * 3];
+  long cnt = 0;
+  for (long i = 0; i < n; i++) {   /* serial: this hook is a checker, not the timed baseline */
+    const float *p = o->src.xyz + 3 * i;
+    float q[3];
+    quat_rot_f(qf, p, q);
+    for (int a = 0; a < 3; a++) q[a] = q[a] + tf[a];
+    float *pl = o->plane + 4 * i;
+    int sel;
+    if (converge) {
+      int m = orc_ivox_knn(o, q, idx, NULL, &buf);
+      sel = m >= o->cfg.min_knn;
+      if (sel) {
+        for (int j = 0; j < m; j++) for (int a = 0; a < 3; a++) near[j * 3 + a] = o->tgt.xyz[3 * (long)idx[j] + a];
+        sel = orc_esti_plane(near, m, K, o->cfg.min_knn, (float)o->cfg.plane_threshold, pl);
+      }
+      o->selected[i] = (unsigned char)sel;   /* plane validity only; the residual test below is re-evaluated every call */
+    } else {
+      sel = o->selected[i];
+    }
+    if (!sel) continue;
+    const float pd2 = pl[0] * q[0] + pl[1] * q[1] + pl[2] * q[2] + pl[3];
+    const float pn = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    if (!(pn > 81.f * pd2 * pd2)) continue;   /* clean semantics: dropped for this call */
+    /* Jacobian row   :674-698 */
+    float pthis[3];
+    for (int a = 0; a < 3; a++) pthis[a] = (offR[a * 3 + 0] * p[0] + offR[a * 3 + 1] * p[1]) + offR[a * 3 + 2] * p[2] + offt[a];
+    float C[3];
+    for (int a = 0; a < 3; a++) C[a] = (Rt[a * 3 + 0] * pl[0] + Rt[a * 3 + 1] * pl[1]) + Rt[a * 3 + 2] * pl[2];
+    /* A = skew(point_this) * C as a matrix-vector product (0*c0 first) */
+    const float A[3] = {(0.f * C[0] + -pthis[2] * C[1]) + pthis[1] * C[2], (pthis[2] * C[0] + 0.f * C[1]) + -pthis[0] * C[2], (-pthis[1] * C[0] + pthis[0] * C[1]) + 0.f * C[2]};
+    float row[12] = {pl[0], pl[1], pl[2], A[0], A[1], A[2], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (extrinsic_est_en) {
+      /* B = (skew(p_be) * off_R^T) * C */
+      const float S[9] = {0.f, -p[2], p[1], p[2], 0.f, -p[0], -p[1], p[0], 0.f};
+      float SM[9];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) SM[a * 3 + b] = (S[a * 3 + 0] * offR[b * 3 + 0] + S[a * 3 + 1] * offR[b * 3 + 1]) + S[a * 3 + 2] * offR[b * 3 + 2];
+      for (int a = 0; a < 3; a++) row[6 + a] = (SM[a * 3 + 0] * C[0] + SM[a * 3 + 1] * C[1]) + SM[a * 3 + 2] * C[2];
+      for (int a = 0; a < 3; a++) row[9 + a] = C[a];
+    }
+    const double hh = -(double)pd2;   /* ekfom_data.h(i) = -residual  :697 */
+    int t = 0;
+    for (int a = 0; a < 12; a++) for (int b = a; b < 12; b++) acc[t++] += (double)row[a] * (double)row[b];
+    for (int a = 0; a < 12; a++) acc[78 + a] += (double)row[a] * hh;
+    acc[90] += hh * hh;
+    cnt++;
+  }
+  free(buf.data);
+  int t = 0;
+  for (int a = 0; a < 12; a++) for (int b = a; b < 12; b++) { HTH[a * 12 + b] = acc[t]; HTH[b * 12 + a] = acc[t]; t++; }
+  for (int a = 0; a < 12; a++) HTh[a] = acc[78 + a];
+  if (sum_h2) *sum_h2 = acc[90];
+  if (n_eff) *n_eff = (int)cnt;
+  o->num_inliers = (int)cnt;
+  return cnt > 0 ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------- */
 /* model dispatch                                                             */
 /* ------------------------------------------------------------------------- */
 static double model_linearize(oracle *o, const double T[16], double *H, double *b) {

@@ -74,6 +74,20 @@ int orc_align(void *h, const float guess[16], orc_result *out);
 void orc_set_trace(void *h, double *buf, int max_records);
 int orc_trace_count(void *h);
 
+/* jueying_lio measurement model (IEKF h_dyn_share callback): state as in state_ikfom,
+ * quaternions in Eigen coefficient order (x, y, z, w). */
+typedef struct orc_lio_state {
+  double rot[4];     /* s.rot            world <- imu */
+  double pos[3];     /* s.pos */
+  double off_R[4];   /* s.offset_R_L_I   imu <- lidar */
+  double off_T[3];   /* s.offset_T_L_I */
+} orc_lio_state;
+/* LaserMapping::ObsModel (jueying_lio/src/laser_mapping.cc:592-701) + the reduction the IEKF
+ * applies to it, HTH = h_x^T h_x and h_x^T h (esekfom.hpp:1687,1706).  converge != 0: re-match
+ * (5-NN + plane fit); converge == 0: re-use the planes of the previous call.  Returns 0, or -1
+ * when there is no effective point (ekfom_data.valid = false, :657-661). */
+int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int converge, double HTH[144], double HTh[12], int *n_eff, double *sum_h2);
+
 /* building blocks exposed for unit pinning */
 void orc_test_so3_exp(const double omega[3], double R[9]);
 void orc_test_ldlt6_solve(const double A[36], const double b[6], double x[6]);

@@ -13,7 +13,7 @@ SYMBOLS = [
     "pcm_abi_version", "pcm_default_config", "pcm_create", "pcm_destroy", "pcm_last_error",
     "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
     "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
-    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
+    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_obs_model", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
@@ -47,6 +47,14 @@ class PcmResult(C.Structure):
                 ("cost", C.c_double), ("iterations", C.c_int32), ("converged", C.c_int32),
                 ("num_linearize", C.c_int32), ("num_compute_error", C.c_int32),
                 ("num_inliers", C.c_int32), ("status", C.c_int32)]
+
+
+class PcmLioState(C.Structure):
+    _fields_ = [("rot", C.c_double * 4), ("pos", C.c_double * 3), ("off_R", C.c_double * 4), ("off_T", C.c_double * 3)]
+
+
+class PcmObsResult(C.Structure):
+    _fields_ = [("HTH", C.c_double * 144), ("HTh", C.c_double * 12), ("sum_h2", C.c_double), ("n_eff", C.c_int32), ("valid", C.c_int32)]
 
 
 class PcmStats(C.Structure):
@@ -110,6 +118,7 @@ def load_library():
     L.pcm_linearize.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.pcm_compute_error.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.pcm_get_planes.argtypes = [vp, vp, sz]
+    L.pcm_obs_model.argtypes = [vp, C.POINTER(PcmLioState), i32, i32, C.POINTER(PcmObsResult)]
     L.pcm_align_batch.argtypes = [C.POINTER(vp), i32, vp, vp, vp]
     L.pcm_set_profiling.argtypes = [vp, i32]
     L.pcm_debug_phase_cycles.argtypes = [vp, vp]

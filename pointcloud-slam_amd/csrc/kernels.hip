@@ -46,6 +46,9 @@ constexpr int kNearby[27][3] = {
   {1, 1, 0},   {-1, 1, 0},  {1, -1, 0},  {-1, -1, 0}, {1, 0, 1},   {-1, 0, 1},  {1, 0, -1},
   {-1, 0, -1}, {0, 1, 1},   {0, -1, 1},  {0, 1, -1},  {0, -1, -1}, {1, 1, 1},   {-1, 1, 1},
   {1, -1, 1},  {1, 1, -1},  {-1, -1, 1}, {-1, 1, -1}, {1, -1, -1}, {-1, -1, -1}};
+// IEKF reduction terms (LIO rows = 12 Jacobian columns, h, selected): 78 x HTH upper triangle, 12 x H^T h, sum h^2, count
+__constant__ int8_t c_lio_a[96] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 8, 8, 8, 8, 9, 9, 9, 10, 10, 11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 0, 0, 0};
+__constant__ int8_t c_lio_b[96] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 3, 4, 5, 6, 7, 8, 9, 10, 11, 4, 5, 6, 7, 8, 9, 10, 11, 5, 6, 7, 8, 9, 10, 11, 6, 7, 8, 9, 10, 11, 7, 8, 9, 10, 11, 8, 9, 10, 11, 9, 10, 11, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 13, 0, 0, 0, 0};
 // term j of the normal equations = row[c_term_a[j]] * row[c_term_b[j]] with row = (J0..J5, e, selected)
 __constant__ int8_t c_term_a[32] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6, 7, 0, 0, 0};
 __constant__ int8_t c_term_b[32] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 0, 0, 0};
@@ -259,7 +262,7 @@ constexpr uint16_t kNoCell = 0xffffu;
     t_prev = t_now;                                                            \
   }
 
-template <bool STATS, bool TIMING, bool WRITE_PLANES>
+template <bool STATS, bool TIMING, bool WRITE_PLANES, bool LIO>
 __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
                                                       unsigned long long* __restrict__ stats) {
   const int pair = blockIdx.y;
@@ -270,6 +273,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
   const bool live = i < d.src.num_points;
   const PoseF P = load_pose(states[pair].x0);
   const TargetView tg = d.tgt;
+  const bool do_search = !LIO || kp.lio_rematch != 0;   // LIO with converge == false re-uses the stored planes (laser_mapping.cc:616)
 
   __shared__ int s_red[4][6];
   __shared__ int s_box[8];                 // origin xyz, dims xyz, ncell, dense flag
@@ -292,275 +296,364 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
   bool search = false;  // lanes whose query voxel lies inside the key range of the table
   if (live) {
     p = gload4(d.src.pts + i);
-    transform(P, p, q);
+    if (LIO) {   // p_w = R_wl * p_body + t_wl with R_wl a float quaternion (Eigen _transformVector)  laser_mapping.cc:602-612
+      const float qx = d.lio.q_wl[0], qy = d.lio.q_wl[1], qz = d.lio.q_wl[2], qw = d.lio.q_wl[3];
+      float uv[3] = {qy * p.z - qz * p.y, qz * p.x - qx * p.z, qx * p.y - qy * p.x};
+      uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+      const float c3[3] = {qy * uv[2] - qz * uv[1], qz * uv[0] - qx * uv[2], qx * uv[1] - qy * uv[0]};
+      q[0] = (p.x + qw * uv[0] + c3[0]) + d.lio.t_wl[0];
+      q[1] = (p.y + qw * uv[1] + c3[1]) + d.lio.t_wl[1];
+      q[2] = (p.z + qw * uv[2] + c3[2]) + d.lio.t_wl[2];
+    } else {
+      transform(P, p, q);
+    }
     const float fx = roundf(q[0] * tg.inv_res), fy = roundf(q[1] * tg.inv_res), fz = roundf(q[2] * tg.inv_res);  // Pos2Grid  ivox3d.h:283-286
     const float lim = (float)(kCoordBias - 32);
     search = fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim;  // also false for NaN
     if (search) { cx = (int)fx; cy = (int)fy; cz = (int)fz; }
   }
 
-  // ---- voxel bounding box of the tile ---------------------------------------------------------
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    const int big = 0x3fffffff;
-    int mn[3] = {search ? cx : big, search ? cy : big, search ? cz : big};
-    int mx[3] = {search ? cx : -big, search ? cy : -big, search ? cz : -big};
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        mn[a] = min(mn[a], __shfl_xor(mn[a], off, 64));
-        mx[a] = max(mx[a], __shfl_xor(mx[a], off, 64));
-      }
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; a++) { s_red[wave][a] = mn[a]; s_red[wave][3 + a] = mx[a]; }
-    }
-  }
-  if (threadIdx.x == 0) s_njobs = 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int ncell = 1;
-    bool ok = kp.use_lds != 0;
-    for (int a = 0; a < 3; a++) {
-      const int mn = min(min(s_red[0][a], s_red[1][a]), min(s_red[2][a], s_red[3][a]));
-      const int mx = max(max(s_red[0][3 + a], s_red[1][3 + a]), max(s_red[2][3 + a], s_red[3][3 + a]));
-      if (mx < mn) { ok = false; s_box[a] = 0; s_box[3 + a] = 0; continue; }  // no searchable lane in this tile
-      const long long dim = (long long)mx - mn + 3;  // +-1 halo for the 27-cell neighbourhood
-      s_box[a] = mn - 1;
-      s_box[3 + a] = (int)(dim < 4096 ? dim : 4096);
-      if (dim > kCapCells) ok = false;
-      ncell = ok ? ncell * (int)dim : ncell;
-      if (ncell > kCapCells) ok = false;
-    }
-    if (ok) {  // bricks under the box
-      int nb = 1;
-      for (int a = 0; a < 3; a++) {
-        const int blo = s_box[a] >> kBrickShift, bhi = (s_box[a] + s_box[3 + a] - 1) >> kBrickShift;
-        s_bbox[a] = blo;
-        s_bbox[3 + a] = bhi - blo + 1;
-        nb *= bhi - blo + 1;
-      }
-      s_bbox[6] = nb;
-      if (nb > kCapBricks) ok = false;
-    }
-    s_box[6] = ncell;
-    s_box[7] = ok ? 1 : 0;
-  }
-  __syncthreads();
-  bool use_lds = s_box[7] != 0;   // uniform over the workgroup
-  PCM_STAMP(0)   // load + transform + tile box
-
-  Best best;
-  best_init(best);
-
-  if (use_lds) {
-    const int ox0 = s_box[0], oy0 = s_box[1], oz0 = s_box[2];
-    const int Dx = s_box[3], Dy = s_box[4], Dz = s_box[5];
-    const int bx0 = s_bbox[0], by0 = s_bbox[1], bz0 = s_bbox[2], nby = s_bbox[4], nbz = s_bbox[5], nb = s_bbox[6];
-    // ---- one probe per BRICK under the box (wave 0), exclusive scan of their point counts -------
-    if (wave == 0) {
-      uint32_t npts = 0, ps = 0;
-      if (lane < nb) {
-        const int z = lane % nbz, xy = lane / nbz, y = xy % nby, x = xy / nby;
-        const uint64_t key = pack_brick(bx0 + x, by0 + y, bz0 + z);
-        uint32_t h = hash_coord(bx0 + x, by0 + y, bz0 + z) & tg.mask;
-        for (;;) {   // both halves of the 32-byte slot in flight together
-          const uint4 s0 = gload4u(&tg.bricks[h]);
-          const uint4 s1 = gload4u(reinterpret_cast<const char*>(&tg.bricks[h]) + 16);
-          if (STATS) n_probe++;
-          const uint64_t sk = slot_key(s0);
-          if (sk == key) { ps = s1.x; npts = s1.y; break; }
-          if (sk == kEmptyKey) break;
-          h = (h + 1) & tg.mask;
+  float4 pl = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+  bool use_lds = false;
+  if (do_search) {
+    // ---- voxel bounding box of the tile ---------------------------------------------------------
+    {
+      const int big = 0x3fffffff;
+      int mn[3] = {search ? cx : big, search ? cy : big, search ? cz : big};
+      int mx[3] = {search ? cx : -big, search ? cy : -big, search ? cz : -big};
+  #pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+  #pragma unroll
+        for (int a = 0; a < 3; a++) {
+          mn[a] = min(mn[a], __shfl_xor(mn[a], off, 64));
+          mx[a] = max(mx[a], __shfl_xor(mx[a], off, 64));
         }
-        // voxel coordinates of the brick's corner relative to the tile box
-        s_borg[lane] = make_int4(((bx0 + x) << kBrickShift) - ox0, ((by0 + y) << kBrickShift) - oy0, ((bz0 + z) << kBrickShift) - oz0, 0);
       }
-      uint32_t incl = npts;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
+      if (lane == 0) {
+  #pragma unroll
+        for (int a = 0; a < 3; a++) { s_red[wave][a] = mn[a]; s_red[wave][3 + a] = mx[a]; }
       }
-      if (lane < nb) { s_bps[lane] = ps; s_boff[lane] = incl - npts; }
-      if (lane == 63) s_boff[kCapBricks] = incl;   // total
     }
-    // meanwhile everybody clears the cell grid
-#pragma unroll
-    for (int j = 0; j < kCapCells / 256; j++) s_cell[threadIdx.x + 256 * j] = kNoCell;
+    if (threadIdx.x == 0) s_njobs = 0;
     __syncthreads();
-    const uint32_t total = s_boff[kCapBricks];
-    use_lds = total <= (uint32_t)kCapPts;   // still uniform
-    PCM_STAMP(1)   // brick probes
-    if (use_lds) {
-      // ---- stage the bricks' map points through LDS: flat, coalesced, all loads in flight --------
-      float4 v[kCapPts / 256];
-      int vb[kCapPts / 256];
-#pragma unroll
-      for (int r = 0; r < kCapPts / 256; r++) {
-        const uint32_t k = threadIdx.x + 256u * r;
-        vb[r] = -1;
-        if (k < total) {
-          int b = 0;
-          while (b + 1 < nb && s_boff[b + 1] <= k) b++;   // nb is small (typically 1..8)
-          vb[r] = b;
-          v[r] = gload4(tg.pts + s_bps[b] + (k - s_boff[b]));
+    if (threadIdx.x == 0) {
+      int ncell = 1;
+      bool ok = kp.use_lds != 0;
+      for (int a = 0; a < 3; a++) {
+        const int mn = min(min(s_red[0][a], s_red[1][a]), min(s_red[2][a], s_red[3][a]));
+        const int mx = max(max(s_red[0][3 + a], s_red[1][3 + a]), max(s_red[2][3 + a], s_red[3][3 + a]));
+        if (mx < mn) { ok = false; s_box[a] = 0; s_box[3 + a] = 0; continue; }  // no searchable lane in this tile
+        const long long dim = (long long)mx - mn + 3;  // +-1 halo for the 27-cell neighbourhood
+        s_box[a] = mn - 1;
+        s_box[3 + a] = (int)(dim < 4096 ? dim : 4096);
+        if (dim > kCapCells) ok = false;
+        ncell = ok ? ncell * (int)dim : ncell;
+        if (ncell > kCapCells) ok = false;
+      }
+      if (ok) {  // bricks under the box
+        int nb = 1;
+        for (int a = 0; a < 3; a++) {
+          const int blo = s_box[a] >> kBrickShift, bhi = (s_box[a] + s_box[3 + a] - 1) >> kBrickShift;
+          s_bbox[a] = blo;
+          s_bbox[3 + a] = bhi - blo + 1;
+          nb *= bhi - blo + 1;
         }
+        s_bbox[6] = nb;
+        if (nb > kCapBricks) ok = false;
       }
-#pragma unroll
-      for (int r = 0; r < kCapPts / 256; r++) {
-        const uint32_t k = threadIdx.x + 256u * r;
-        if (k < total) s_pts[k] = v[r];
+      s_box[6] = ncell;
+      s_box[7] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    use_lds = s_box[7] != 0;   // uniform over the workgroup
+    PCM_STAMP(0)   // load + transform + tile box
+
+    Best best;
+    best_init(best);
+
+    if (use_lds) {
+      const int ox0 = s_box[0], oy0 = s_box[1], oz0 = s_box[2];
+      const int Dx = s_box[3], Dy = s_box[4], Dz = s_box[5];
+      const int bx0 = s_bbox[0], by0 = s_bbox[1], bz0 = s_bbox[2], nby = s_bbox[4], nbz = s_bbox[5], nb = s_bbox[6];
+      // ---- one probe per BRICK under the box (wave 0), exclusive scan of their point counts -------
+      if (wave == 0) {
+        uint32_t npts = 0, ps = 0;
+        if (lane < nb) {
+          const int z = lane % nbz, xy = lane / nbz, y = xy % nby, x = xy / nby;
+          const uint64_t key = pack_brick(bx0 + x, by0 + y, bz0 + z);
+          uint32_t h = hash_coord(bx0 + x, by0 + y, bz0 + z) & tg.mask;
+          for (;;) {   // both halves of the 32-byte slot in flight together
+            const uint4 s0 = gload4u(&tg.bricks[h]);
+            const uint4 s1 = gload4u(reinterpret_cast<const char*>(&tg.bricks[h]) + 16);
+            if (STATS) n_probe++;
+            const uint64_t sk = slot_key(s0);
+            if (sk == key) { ps = s1.x; npts = s1.y; break; }
+            if (sk == kEmptyKey) break;
+            h = (h + 1) & tg.mask;
+          }
+          // voxel coordinates of the brick's corner relative to the tile box
+          s_borg[lane] = make_int4(((bx0 + x) << kBrickShift) - ox0, ((by0 + y) << kBrickShift) - oy0, ((bz0 + z) << kBrickShift) - oz0, 0);
+        }
+        uint32_t incl = npts;
+  #pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t v = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += v;
+        }
+        if (lane < nb) { s_bps[lane] = ps; s_boff[lane] = incl - npts; }
+        if (lane == 63) s_boff[kCapBricks] = incl;   // total
       }
+      // meanwhile everybody clears the cell grid
+  #pragma unroll
+      for (int j = 0; j < kCapCells / 256; j++) s_cell[threadIdx.x + 256 * j] = kNoCell;
       __syncthreads();
-      PCM_STAMP(2)   // stage map points
-      // ---- every voxel head among the staged points registers itself in the cell grid ------------
-#pragma unroll
-      for (int r = 0; r < kCapPts / 256; r++) {
-        const uint32_t k = threadIdx.x + 256u * r;
-        if (k < total) {
-          const int tag = __float_as_int(v[r].w);
-          const bool head = k == s_boff[vb[r]] || __float_as_int(s_pts[k - 1].w) != tag;
-          if (head) {
-            const int4 o = s_borg[vb[r]];
-            const int li = tag & 511;
-            const int x = o.x + (li >> 6), y = o.y + ((li >> 3) & 7), z = o.z + (li & 7);
-            if (x >= 0 && x < Dx && y >= 0 && y < Dy && z >= 0 && z < Dz) s_cell[(x * Dy + y) * Dz + z] = (uint16_t)k;
+      const uint32_t total = s_boff[kCapBricks];
+      use_lds = total <= (uint32_t)kCapPts;   // still uniform
+      PCM_STAMP(1)   // brick probes
+      if (use_lds) {
+        // ---- stage the bricks' map points through LDS: flat, coalesced, all loads in flight --------
+        float4 v[kCapPts / 256];
+        int vb[kCapPts / 256];
+  #pragma unroll
+        for (int r = 0; r < kCapPts / 256; r++) {
+          const uint32_t k = threadIdx.x + 256u * r;
+          vb[r] = -1;
+          if (k < total) {
+            int b = 0;
+            while (b + 1 < nb && s_boff[b + 1] <= k) b++;   // nb is small (typically 1..8)
+            vb[r] = b;
+            v[r] = gload4(tg.pts + s_bps[b] + (k - s_boff[b]));
           }
         }
-      }
-      __syncthreads();
-      PCM_STAMP(3)   // cell grid
-      // ---- per-lane 27-cell / 5-NN search out of LDS (reference cell order) ----------------------
-      if (search) {
-        // all 27 cell heads first (independent LDS reads, one wait), then the occupied cells in
-        // reference order; inside a voxel the next staged point is fetched while the current one
-        // is offered, so a candidate costs one overlapped LDS read instead of two serial ones
-        const int DyDz = Dy * Dz;
-        const int cell0 = ((cx - ox0) * Dy + (cy - oy0)) * Dz + (cz - oz0);
-        uint16_t kh[27];
-#pragma unroll
-        for (int g = 0; g < 27; g++) {
-          kh[g] = kNoCell;
-          if (g < kp.num_neighbors) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
+  #pragma unroll
+        for (int r = 0; r < kCapPts / 256; r++) {
+          const uint32_t k = threadIdx.x + 256u * r;
+          if (k < total) s_pts[k] = v[r];
         }
-        const uint32_t last = total - 1;
-#pragma unroll
-        for (int g = 0; g < 27; g++) {
-          if (kh[g] != kNoCell) {
-            uint32_t k = kh[g];
-            float4 mp = s_pts[k];
-            const int tag = __float_as_int(mp.w);
-            for (;;) {
-              const float4 nx = s_pts[k < last ? k + 1 : last];
-              if (STATS) n_cand++;
-              best_offer(best, mp, q, k, kp.max_range_sq);
-              if (k >= last || __float_as_int(nx.w) != tag) break;
-              mp = nx;
-              k++;
+        __syncthreads();
+        PCM_STAMP(2)   // stage map points
+        // ---- every voxel head among the staged points registers itself in the cell grid ------------
+  #pragma unroll
+        for (int r = 0; r < kCapPts / 256; r++) {
+          const uint32_t k = threadIdx.x + 256u * r;
+          if (k < total) {
+            const int tag = __float_as_int(v[r].w);
+            const bool head = k == s_boff[vb[r]] || __float_as_int(s_pts[k - 1].w) != tag;
+            if (head) {
+              const int4 o = s_borg[vb[r]];
+              const int li = tag & 511;
+              const int x = o.x + (li >> 6), y = o.y + ((li >> 3) & 7), z = o.z + (li & 7);
+              if (x >= 0 && x < Dx && y >= 0 && y < Dy && z >= 0 && z < Dz) s_cell[(x * Dy + y) * Dz + z] = (uint16_t)k;
+            }
+          }
+        }
+        __syncthreads();
+        PCM_STAMP(3)   // cell grid
+        // ---- per-lane 27-cell / 5-NN search out of LDS (reference cell order) ----------------------
+        if (search) {
+          // all 27 cell heads first (independent LDS reads, one wait), then the occupied cells in
+          // reference order; inside a voxel the next staged point is fetched while the current one
+          // is offered, so a candidate costs one overlapped LDS read instead of two serial ones
+          const int DyDz = Dy * Dz;
+          const int cell0 = ((cx - ox0) * Dy + (cy - oy0)) * Dz + (cz - oz0);
+          uint16_t kh[27];
+  #pragma unroll
+          for (int g = 0; g < 27; g++) {
+            kh[g] = kNoCell;
+            if (g < kp.num_neighbors) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
+          }
+          const uint32_t last = total - 1;
+  #pragma unroll
+          for (int g = 0; g < 27; g++) {
+            if (kh[g] != kNoCell) {
+              uint32_t k = kh[g];
+              float4 mp = s_pts[k];
+              const int tag = __float_as_int(mp.w);
+              for (;;) {
+                const float4 nx = s_pts[k < last ? k + 1 : last];
+                if (STATS) n_cand++;
+                best_offer(best, mp, q, k, kp.max_range_sq);
+                if (k >= last || __float_as_int(nx.w) != tag) break;
+                mp = nx;
+                k++;
+              }
             }
           }
         }
       }
     }
-  }
-  if (!use_lds && search) knn_global<STATS>(tg, q, cx, cy, cz, kp.num_neighbors, kp.max_range_sq, best, n_cand, n_probe);
-  PCM_STAMP(4)   // 27-cell / 5-NN search
+    if (!use_lds && search) knn_global<STATS>(tg, q, cx, cy, cz, kp.num_neighbors, kp.max_range_sq, best, n_cand, n_probe);
+    PCM_STAMP(4)   // 27-cell / 5-NN search
 
-  // ---- plane fit on the <= 5 neighbours  (laser_mapping.cc:619-623) -----------------------------
-  // 5 neighbours (the float path, almost every lane) is solved in place; the rare
-  // 3- and 4-neighbour cases (double path) are queued and solved by the first lanes
-  // of the workgroup afterwards, so one straggler does not drag its whole wave
-  // through the double-precision QR.
-  float4 pl = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
-  uint32_t my_job = ~0u;
-  if (live) {
-    if (best.m == K) {
+    // ---- plane fit on the <= 5 neighbours  (laser_mapping.cc:619-623) -----------------------------
+    // 5 neighbours (the float path, almost every lane) is solved in place; the rare
+    // 3- and 4-neighbour cases (double path) are queued and solved by the first lanes
+    // of the workgroup afterwards, so one straggler does not drag its whole wave
+    // through the double-precision QR.
+    uint32_t my_job = ~0u;
+    if (live) {
+      if (best.m == K) {
+        float px[K], py[K], pz[K];
+  #pragma unroll
+        for (int j = 0; j < K; j++) {
+          const float4 mp = use_lds ? s_pts[best.i[j]] : gload4(tg.pts + best.i[j]);
+          px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
+        }
+        float4 fit;
+        if (esti_plane(px, py, pz, K, kp.plane_threshold, &fit)) pl = fit;
+      } else if (best.m >= KMIN) {
+        my_job = atomicAdd(&s_njobs, 1u);
+        s_job[my_job] = threadIdx.x | ((uint32_t)best.m << 16);
+  #pragma unroll
+        for (int j = 0; j < 4; j++) s_jobid[my_job][j] = best.i[j];
+      }
+    }
+    PCM_STAMP(5)   // float plane fit
+    __syncthreads();
+    const uint32_t njobs = s_njobs;
+    for (uint32_t job = threadIdx.x; job < njobs; job += 256) {
+      const uint32_t m = s_job[job] >> 16;
       float px[K], py[K], pz[K];
-#pragma unroll
+  #pragma unroll
       for (int j = 0; j < K; j++) {
-        const float4 mp = use_lds ? s_pts[best.i[j]] : gload4(tg.pts + best.i[j]);
+        float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < (int)m) mp = use_lds ? s_pts[s_jobid[job][j]] : gload4(tg.pts + s_jobid[job][j]);
         px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
       }
       float4 fit;
-      if (esti_plane(px, py, pz, K, kp.plane_threshold, &fit)) pl = fit;
-    } else if (best.m >= KMIN) {
-      my_job = atomicAdd(&s_njobs, 1u);
-      s_job[my_job] = threadIdx.x | ((uint32_t)best.m << 16);
-#pragma unroll
-      for (int j = 0; j < 4; j++) s_jobid[my_job][j] = best.i[j];
+      if (!esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) fit.x = __builtin_nanf("");
+      s_jobid[job][0] = __float_as_uint(fit.x); s_jobid[job][1] = __float_as_uint(fit.y);   // hand the plane back to its owner lane
+      s_jobid[job][2] = __float_as_uint(fit.z); s_jobid[job][3] = __float_as_uint(fit.w);
     }
+    __syncthreads();   // also: nobody reads s_pts after this point (its memory is re-used below)
+    if (my_job != ~0u) pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
+  } else {
+    if (live) pl = gload4(d.planes + i);   // plane of the previous ObsModel call (NaN: none)
+    __syncthreads();
   }
-  PCM_STAMP(5)   // float plane fit
-  __syncthreads();
-  const uint32_t njobs = s_njobs;
-  for (uint32_t job = threadIdx.x; job < njobs; job += 256) {
-    const uint32_t m = s_job[job] >> 16;
-    float px[K], py[K], pz[K];
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < (int)m) mp = use_lds ? s_pts[s_jobid[job][j]] : gload4(tg.pts + s_jobid[job][j]);
-      px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
-    }
-    float4 fit;
-    if (!esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) fit.x = __builtin_nanf("");
-    s_jobid[job][0] = __float_as_uint(fit.x); s_jobid[job][1] = __float_as_uint(fit.y);   // hand the plane back to its owner lane
-    s_jobid[job][2] = __float_as_uint(fit.z); s_jobid[job][3] = __float_as_uint(fit.w);
-  }
-  __syncthreads();   // also: nobody reads s_pts after this point (its memory is re-used below)
-  if (my_job != ~0u) pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
 
-  // ---- residual / Jacobian of this lane's point -> one 8-float row in LDS ---------------------------
-  // (the LDS of s_pts is free now: nobody reads map points after the barrier above)
-  float* s_row = reinterpret_cast<float*>(s_pts);                       // [256][8]: J0..J5, e, selected
-  double* s_grp = reinterpret_cast<double*>(s_row + 256 * 8);           // [8][32] group partials
-  {
-    float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      bool sel = !(pl.x != pl.x);
-      if (sel) {
-        const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
-        const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
-        sel = pn > 81.f * pd2 * pd2;                                       // :631
+  if constexpr (LIO) {
+    // ---- jueying_lio measurement row (laser_mapping.cc:674-698) -> 16-float row in LDS; the IEKF's
+    //      HTH = h_x^T h_x and h_x^T h (esekfom.hpp:1687,1706) are reduced here: 92 sums per tile
+    float* s_row = reinterpret_cast<float*>(s_pts);                     // [256][16]: 12 columns, h, selected
+    double* s_grp = reinterpret_cast<double*>(s_row + 256 * 16);        // [8][96] group partials
+    {
+      float row[16];
+#pragma unroll
+      for (int a = 0; a < 16; a++) row[a] = 0.f;
+      if (live) {
+        bool sel = !(pl.x != pl.x);
+        if (do_search) gstore4(d.planes + i, pl);                        // plane_coef_[i]; the residual test is re-evaluated every call
         if (sel) {
-          // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
-          row[0] = q[1] * pl.z - q[2] * pl.y;
-          row[1] = q[2] * pl.x - q[0] * pl.z;
-          row[2] = q[0] * pl.y - q[1] * pl.x;
-          row[3] = pl.x; row[4] = pl.y; row[5] = pl.z;
-          row[6] = pd2;
-          row[7] = 1.f;
+          const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
+          const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+          sel = pn > 81.f * pd2 * pd2;
+          if (sel) {
+            const float* oR = d.lio.off_R;
+            const float* Rt = d.lio.Rt;
+            float pt[3], C[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) pt[a] = (oR[a * 3 + 0] * p.x + oR[a * 3 + 1] * p.y) + oR[a * 3 + 2] * p.z + d.lio.off_t[a];   // point_this
+#pragma unroll
+            for (int a = 0; a < 3; a++) C[a] = (Rt[a * 3 + 0] * pl.x + Rt[a * 3 + 1] * pl.y) + Rt[a * 3 + 2] * pl.z;               // C = R^T n
+            row[0] = pl.x; row[1] = pl.y; row[2] = pl.z;
+            row[3] = (0.f * C[0] + -pt[2] * C[1]) + pt[1] * C[2];                                                                 // A = skew(point_this) C
+            row[4] = (pt[2] * C[0] + 0.f * C[1]) + -pt[0] * C[2];
+            row[5] = (-pt[1] * C[0] + pt[0] * C[1]) + 0.f * C[2];
+            if (kp.lio_extrinsic) {   // B = (skew(p_body) off_R^T) C ; then C
+              const float S[9] = {0.f, -p.z, p.y, p.z, 0.f, -p.x, -p.y, p.x, 0.f};
+#pragma unroll
+              for (int a = 0; a < 3; a++) {
+                float sm[3];
+#pragma unroll
+                for (int b = 0; b < 3; b++) sm[b] = (S[a * 3 + 0] * oR[b * 3 + 0] + S[a * 3 + 1] * oR[b * 3 + 1]) + S[a * 3 + 2] * oR[b * 3 + 2];
+                row[6 + a] = (sm[0] * C[0] + sm[1] * C[1]) + sm[2] * C[2];
+                row[9 + a] = C[a];
+              }
+            }
+            row[12] = -pd2;    // ekfom_data.h(i) = -residual
+            row[13] = 1.f;
+          }
         }
       }
-      if (WRITE_PLANES) gstore4(d.planes + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
-    }
-    float4* dst = reinterpret_cast<float4*>(s_row + threadIdx.x * 8);
-    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
-  }
-  __syncthreads();
-  // ---- 29 sums over the tile's 256 rows: thread (group g, term j) adds 32 rows in double ------------
-  // term j = row[ia] * row[ib]: 21 x H upper triangle, 6 x b = J e, cost = e e, count = sel sel
-  {
-    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double v = 0.0;
-    if (j < kNumSums) {
-      const int ia = c_term_a[j], ib = c_term_b[j];
-      const float* r0 = s_row + (g * 32) * 8;
-#pragma unroll 8
-      for (int k = 0; k < 32; k++) v = fma((double)r0[k * 8 + ia], (double)r0[k * 8 + ib], v);
-    }
-    s_grp[g * kPartialStride + j] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNumSums) {
-    double v = 0.0;
+      float4* dst = reinterpret_cast<float4*>(s_row + threadIdx.x * 16);
 #pragma unroll
-    for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
-    gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+      for (int a = 0; a < 4; a++) dst[a] = make_float4(row[4 * a], row[4 * a + 1], row[4 * a + 2], row[4 * a + 3]);
+    }
+    __syncthreads();
+    {
+      const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+      const float* r0 = s_row + (g * 32) * 16;
+#pragma unroll
+      for (int tt = 0; tt < 3; tt++) {
+        const int term = j + 32 * tt;
+        if (term < kLioSums) {
+          const int ia = c_lio_a[term], ib = c_lio_b[term];
+          double v = 0.0;
+#pragma unroll 8
+          for (int k = 0; k < 32; k++) v = fma((double)r0[k * 16 + ia], (double)r0[k * 16 + ib], v);
+          s_grp[g * kLioStride + term] = v;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kLioSums) {
+      double v = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; g++) v += s_grp[g * kLioStride + threadIdx.x];
+      gstore_d(d.partials + (size_t)blockIdx.x * kLioStride + threadIdx.x, v);
+    }
+  } else {
+    // ---- residual / Jacobian of this lane's point -> one 8-float row in LDS ---------------------------
+    // (the LDS of s_pts is free now: nobody reads map points after the barrier above)
+    float* s_row = reinterpret_cast<float*>(s_pts);                       // [256][8]: J0..J5, e, selected
+    double* s_grp = reinterpret_cast<double*>(s_row + 256 * 8);           // [8][32] group partials
+    {
+      float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (live) {
+        bool sel = !(pl.x != pl.x);
+        if (sel) {
+          const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
+          const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+          sel = pn > 81.f * pd2 * pd2;                                       // :631
+          if (sel) {
+            // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
+            row[0] = q[1] * pl.z - q[2] * pl.y;
+            row[1] = q[2] * pl.x - q[0] * pl.z;
+            row[2] = q[0] * pl.y - q[1] * pl.x;
+            row[3] = pl.x; row[4] = pl.y; row[5] = pl.z;
+            row[6] = pd2;
+            row[7] = 1.f;
+          }
+        }
+        if (WRITE_PLANES) gstore4(d.planes + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
+      }
+      float4* dst = reinterpret_cast<float4*>(s_row + threadIdx.x * 8);
+      dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+      dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+    }
+    __syncthreads();
+    // ---- 29 sums over the tile's 256 rows: thread (group g, term j) adds 32 rows in double ------------
+    // term j = row[ia] * row[ib]: 21 x H upper triangle, 6 x b = J e, cost = e e, count = sel sel
+    {
+      const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+      double v = 0.0;
+      if (j < kNumSums) {
+        const int ia = c_term_a[j], ib = c_term_b[j];
+        const float* r0 = s_row + (g * 32) * 8;
+  #pragma unroll 8
+        for (int k = 0; k < 32; k++) v = fma((double)r0[k * 8 + ia], (double)r0[k * 8 + ib], v);
+      }
+      s_grp[g * kPartialStride + j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumSums) {
+      double v = 0.0;
+  #pragma unroll
+      for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
+      gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+    }
   }
   PCM_STAMP(6)   // queued double-precision fits + residual + workgroup reduction
   if (TIMING && threadIdx.x == 0) atomicAdd(&stats[15], 1ull);
@@ -579,11 +672,38 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
 void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                       unsigned long long* d_stats, bool timing) {
   dim3 grid((unsigned)kp.tiles_per_pair, (unsigned)npairs);
-#define PCM_LAUNCH(S, T, W) k_linearize<S, T, W><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats)
+#define PCM_LAUNCH(S, T, W) k_linearize<S, T, W, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, d_stats)
   if (d_stats && timing) { if (write_planes) PCM_LAUNCH(false, true, true); else PCM_LAUNCH(false, true, false); }
   else if (d_stats) { if (write_planes) PCM_LAUNCH(true, false, true); else PCM_LAUNCH(true, false, false); }
   else { if (write_planes) PCM_LAUNCH(false, false, true); else PCM_LAUNCH(false, false, false); }
 #undef PCM_LAUNCH
+}
+
+// jueying_lio measurement model: same search kernel, 12-column rows, IEKF reduction
+void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp) {
+  dim3 grid((unsigned)kp.tiles_per_pair, 1u);
+  k_linearize<false, false, true, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, nullptr);
+}
+
+// fixed-order sum of the LIO partial rows -> 96 doubles (78 HTH, 12 HTh, sum h^2, count)
+__global__ void __launch_bounds__(1024) k_lio_finish(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+  __shared__ double s_grp[10 * kLioStride];
+  const int t = threadIdx.x % kLioStride, r = threadIdx.x / kLioStride;   // 10 row groups x 96 columns (960 threads)
+  if (r < 10) {
+    double v = 0.0;
+    if (t < kLioSums) for (int b = r; b < nblocks; b += 10) v += gload_d(partials + (size_t)b * kLioStride + t);
+    s_grp[r * kLioStride + t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLioSums) {
+    double v = 0.0;
+    for (int k = 0; k < 10; k++) v += s_grp[k * kLioStride + threadIdx.x];
+    out[threadIdx.x] = v;
+  }
+}
+
+void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out) {
+  k_lio_finish<<<1, 1024, 0, stream>>>(d_partials, nblocks, d_out);
 }
 
 // ---------------------------------------------------------------------------

@@ -562,6 +562,7 @@ int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   if (tag != 0 && tag == c->src.tag && c->src.n == n) return PCM_OK;  // fast_gicp_impl.hpp:72-74
   int rc = set_cloud(c, &c->src, points, n, stride_bytes, memory, tag, true);
   c->src_sorted = false;
+  c->lio_planes_valid = false;
   c->srcmap.valid = false;
   return rc;
 }
@@ -635,6 +636,99 @@ int pcm_compute_error(pcm_ctx* c, const double T[16], double* cost) {
   int rc = single_pass(c, T, false, s);
   if (rc != PCM_OK) return rc;
   *cost = s[27];
+  return PCM_OK;
+}
+
+namespace {
+void quat_mul_d(const double* a, const double* b, double* r) {   // Eigen quaternion product, (x,y,z,w)
+  r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+void quat_rot_d(const double* q, const double* v, double* r) {   // Eigen _transformVector
+  double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+  for (int a = 0; a < 3; a++) r[a] = v[a] + q[3] * uv[a] + c[a];
+}
+void quat_to_rot_d(const double* q, double* R) {   // Eigen Quaternion::toRotationMatrix, row-major
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+}  // namespace
+
+int pcm_obs_model(pcm_ctx* c, const pcm_lio_state* s, int extrinsic_est_en, int rematch, pcm_obs_result* out) {
+  CHECK_CTX(c);
+  if (!s || !out) return PCM_ERR_INVALID_ARGUMENT;
+  if (c->cfg.model != PCM_MODEL_P2PLANE) { c->err = "pcm_obs_model needs the P2PLANE model"; return PCM_ERR_INVALID_ARGUMENT; }
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  rc = prepare(c);
+  if (rc != PCM_OK) return rc;
+  if (!rematch && !c->lio_planes_valid) { c->err = "pcm_obs_model(rematch=0) before any matching call"; return PCM_ERR_INVALID_ARGUMENT; }
+  // the float state exactly as the reference casts it (laser_mapping.cc:602-603,669-671)
+  LioPose L{};
+  double qwl[4], twl[3], Rd[9], ORd[9];
+  quat_mul_d(s->rot, s->off_R, qwl);
+  quat_rot_d(s->rot, s->off_T, twl);
+  quat_to_rot_d(s->rot, Rd);
+  quat_to_rot_d(s->off_R, ORd);
+  for (int a = 0; a < 4; a++) L.q_wl[a] = (float)qwl[a];
+  for (int a = 0; a < 3; a++) { L.t_wl[a] = (float)(twl[a] + s->pos[a]); L.off_t[a] = (float)s->off_T[a]; }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { L.Rt[i * 3 + j] = (float)Rd[j * 3 + i]; L.off_R[i * 3 + j] = (float)ORd[i * 3 + j]; }
+
+  const uint32_t n = (uint32_t)c->src.n;
+  const int tiles = (int)((n + 255u) / 256u);
+  Workspace* w = nullptr;
+  rc = ensure_ws(c, &w, 1, (size_t)tiles * kLioStride, 2);
+  if (rc != PCM_OK) return rc;
+  hipStream_t st = c->stream;
+  if (c->cfg.sort_source && !c->src_sorted) {   // new scan: order it along the world grid at this state's pose
+    double Rwl[9];
+    quat_to_rot_d(qwl, Rwl);
+    float g[16] = {(float)Rwl[0], (float)Rwl[1], (float)Rwl[2], L.t_wl[0], (float)Rwl[3], (float)Rwl[4], (float)Rwl[5], L.t_wl[1],
+                   (float)Rwl[6], (float)Rwl[7], (float)Rwl[8], L.t_wl[2], 0.f, 0.f, 0.f, 1.f};
+    SortJob j{c->src.d_pts, c->src_order, n, 0, 0, 0};
+    HIPCK(c, hipMemcpyAsync(w->d_guesses, g, sizeof(g), hipMemcpyHostToDevice, st));
+    HIPCK(c, hipMemcpyAsync(w->d_jobs, &j, sizeof(j), hipMemcpyHostToDevice, st));
+    rc = sort_sources_batched(st, w->d_jobs, 1, n, n, w->d_guesses, c->cfg.voxel_resolution, &w->sort, &c->err);
+    if (rc != PCM_OK) return rc;
+    c->src_sorted = true;
+    c->lio_planes_valid = false;
+    if (!rematch) { c->err = "pcm_obs_model(rematch=0) on a new scan"; return PCM_ERR_INVALID_ARGUMENT; }
+  }
+  Geom geom = pick_geom(n, 1);
+  KernelParams kp = kernel_params(c->cfg, geom);
+  kp.lio_rematch = rematch ? 1 : 0;
+  kp.lio_extrinsic = extrinsic_est_en ? 1 : 0;
+  PairDesc d;
+  fill_desc(c, &d, w->d_partials);
+  d.lio = L;
+  PairState ps;
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  init_state(ps, ident);
+  HIPCK(c, hipMemcpyAsync(w->d_descs, &d, sizeof(d), hipMemcpyHostToDevice, st));
+  HIPCK(c, hipMemcpyAsync(w->d_states, &ps, sizeof(ps), hipMemcpyHostToDevice, st));
+  launch_lio_obs(st, w->d_descs, w->d_states, kp);
+  launch_lio_finish(st, w->d_partials, tiles, w->d_sums);
+  HIPCK(c, hipGetLastError());
+  double sums[kLioStride];
+  HIPCK(c, hipMemcpyAsync(sums, w->d_sums, sizeof(double) * kLioStride, hipMemcpyDeviceToHost, st));
+  HIPCK(c, hipStreamSynchronize(st));
+  if (rematch) c->lio_planes_valid = true;
+  int t = 0;
+  for (int a = 0; a < 12; a++) for (int b = a; b < 12; b++) { out->HTH[a * 12 + b] = sums[t]; out->HTH[b * 12 + a] = sums[t]; t++; }
+  for (int a = 0; a < 12; a++) out->HTh[a] = sums[78 + a];
+  out->sum_h2 = sums[90];
+  out->n_eff = (int32_t)sums[91];
+  out->valid = out->n_eff >= 1 ? 1 : 0;
+  c->stats.linearize_launches += 1;
+  c->stats.point_passes += n;
   return PCM_OK;
 }
 

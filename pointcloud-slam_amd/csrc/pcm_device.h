@@ -125,11 +125,23 @@ struct SourceView {
   uint32_t num_points;       // number of source elements
 };
 
+// jueying_lio state for the measurement model (floats, prepared on the host exactly as
+// laser_mapping.cc:602-603,669-671 cast them)
+struct LioPose {
+  float q_wl[4];     // (s.rot * s.offset_R_L_I).cast<float>(), Eigen coefficient order x,y,z,w
+  float t_wl[3];     // (s.rot * s.offset_T_L_I + s.pos).cast<float>()
+  float off_t[3];    // s.offset_T_L_I
+  float off_R[9];    // s.offset_R_L_I.toRotationMatrix()      (row-major)
+  float Rt[9];       // s.rot.toRotationMatrix().transpose()
+  float pad[2];
+};
+
 // per-pair descriptor read by the residual kernels
 struct PairDesc {
   TargetView tgt;
   SourceView src;
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
+  LioPose lio;          // LIO measurement model only
   int32_t* corr;        // NDT: [elements][offsets] matched target voxel (or -1) of the last linearize
   double* partials;     // [workgroups of the round][kPartialStride]
   unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)
@@ -137,6 +149,8 @@ struct PairDesc {
 
 constexpr int kNumSums = 29;        // 21 (H upper) + 6 (b) + cost + inlier count
 constexpr int kPartialStride = 32;  // doubles per block partial (padded)
+constexpr int kLioSums = 92;        // 78 (HTH upper) + 12 (H^T h) + sum h^2 + count
+constexpr int kLioStride = 96;
 
 struct KernelParams {
   int32_t num_neighbors;
@@ -149,6 +163,8 @@ struct KernelParams {
   int32_t tiles_per_pair;     // k_linearize grid.x (256-point tiles)
   int32_t use_lds;            // 0: always probe the global table per lane (A/B and parity checks)
   int32_t do_step;            // 1: k_finish_round runs the GN/LM step; 0: it exports the sums (parity hooks)
+  int32_t lio_rematch;        // LIO: ekfom_data.converge (1: search + plane fit, 0: re-use the stored planes)
+  int32_t lio_extrinsic;      // LIO: extrinsic_est_en (columns 6..11 of h_x)
   int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)
 };
 

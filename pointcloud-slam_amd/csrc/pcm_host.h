@@ -80,6 +80,8 @@ struct LaunchGeom {
 };
 void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                       unsigned long long* d_stats, bool timing);
+void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp);
+void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out);
 void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs);
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
                          bool write_flags, unsigned char* d_flags_row, double* d_sums);
@@ -108,6 +110,7 @@ struct pcm_ctx {
   std::string err;
   pcm_stats stats{};
   uint64_t phase_cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic (profiling bit2)
+  bool lio_planes_valid = false;   // planes of the last pcm_obs_model(rematch=1) belong to the current scan
   void* ws = nullptr;   // batch workspace owned by this context (pcm_api.hip)
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };

@@ -149,6 +149,15 @@ class Registration:
         self._check(self._L.pcm_compute_error(self._h, T.ctypes.data, C.byref(cost)))
         return cost.value
 
+    def obs_model(self, rot_xyzw, pos, off_R_xyzw, off_T, extrinsic_est_en=False, converge=True):
+        """jueying_lio's ObsModel + the IEKF reduction (pcm_obs_model):
+        returns (HTH 12x12, HTh 12, n_eff, sum_h2, valid)."""
+        st = capi.PcmLioState()
+        st.rot[:] = list(rot_xyzw); st.pos[:] = list(pos); st.off_R[:] = list(off_R_xyzw); st.off_T[:] = list(off_T)
+        out = capi.PcmObsResult()
+        self._check(self._L.pcm_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), C.byref(out)))
+        return np.array(out.HTH[:]).reshape(12, 12), np.array(out.HTh[:]), out.n_eff, out.sum_h2, bool(out.valid)
+
     def get_planes(self, n: int) -> np.ndarray:
         """(n,4) planes fitted by the last evaluate_cost (NaN row = point not selected)."""
         out = np.zeros((n, 4), np.float32)
