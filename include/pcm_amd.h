@@ -89,7 +89,8 @@ typedef struct pcm_config {
   int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
   int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
   int32_t flags;                 /* PCM_FLAG_* (speed / debugging only, never changes a result) */
-  int32_t reserved[6];
+  int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
+  int32_t reserved[5];
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
@@ -195,6 +196,20 @@ typedef struct pcm_obs_result {
 } pcm_obs_result;
 
 int pcm_obs_model(pcm_ctx *ctx, const pcm_lio_state *state, int extrinsic_est_en, int rematch, pcm_obs_result *out);
+
+/* Sliding submap (jueying_lio): IVox::AddPoints (jueying_lio/include/ivox3d/ivox3d.h:256-281) --
+ * append points to the target; voxels beyond cfg.map_capacity are dropped least-recently-
+ * touched first.  The voxel hash is rebuilt on the device at the next matching call. */
+int pcm_target_insert(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory);
+
+/* LaserMapping::MapIncremental (jueying_lio/src/laser_mapping.cc:525-583): transform the current
+ * scan with the updated state (PointBodyToWorld, :855-864), apply the map add-filter against the
+ * neighbours found by the last pcm_obs_model(rematch != 0), and insert the survivors
+ * (points_to_add first, then point_no_need_downsample).  ekf_inited = flg_EKF_inited_. */
+int pcm_map_incremental(pcm_ctx *ctx, const pcm_lio_state *state, float filter_size_map, int ekf_inited, size_t *num_added);
+
+/* current target points in insertion order (x,y,z per point); *n receives the count (query with out = NULL) */
+int pcm_get_target(pcm_ctx *ctx, float *out_xyz, size_t capacity_points, size_t *n);
 
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel

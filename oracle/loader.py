@@ -22,7 +22,7 @@ class OracleConfig(C.Structure):
                 ("voxel_resolution", C.c_double), ("num_neighbors", C.c_int), ("knn", C.c_int),
                 ("min_knn", C.c_int), ("max_range", C.c_double), ("plane_threshold", C.c_double),
                 ("max_corr_dist", C.c_double), ("k_correspondences", C.c_int),
-                ("regularization", C.c_int), ("num_threads", C.c_int)]
+                ("regularization", C.c_int), ("num_threads", C.c_int), ("map_capacity", C.c_long)]
 
 
 class LioState(C.Structure):
@@ -61,6 +61,13 @@ def lib():
         L.orc_num_inliers.argtypes = [C.c_void_p]
         L.orc_get_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
         L.orc_obs_model.argtypes = [C.c_void_p, C.POINTER(LioState), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.orc_target_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long]
+        L.orc_map_incremental.argtypes = [C.c_void_p, C.POINTER(LioState), C.c_double, C.c_int, C.POINTER(C.c_long)]
+        L.orc_target_size.restype = C.c_long
+        L.orc_target_size.argtypes = [C.c_void_p]
+        L.orc_target_voxels.restype = C.c_long
+        L.orc_target_voxels.argtypes = [C.c_void_p]
+        L.orc_get_target.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_align.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OracleResult)]
         L.orc_set_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace_count.argtypes = [C.c_void_p]
@@ -143,6 +150,28 @@ class Oracle:
         HTH = np.zeros((12, 12)); HTh = np.zeros(12); n = C.c_int(); s2 = C.c_double()
         lib().orc_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), HTH.ctypes.data, HTh.ctypes.data, C.byref(n), C.byref(s2))
         return HTH, HTh, n.value, s2.value
+
+    def target_insert(self, pts):
+        a = _f32(pts)
+        lib().orc_target_insert(self._h, a.ctypes.data, a.shape[0], a.shape[1])
+
+    def map_incremental(self, rot_xyzw, pos, off_R_xyzw, off_T, filter_size_map, ekf_inited=True):
+        st = LioState()
+        st.rot[:] = list(rot_xyzw); st.pos[:] = list(pos); st.off_R[:] = list(off_R_xyzw); st.off_T[:] = list(off_T)
+        n = C.c_long()
+        lib().orc_map_incremental(self._h, C.byref(st), float(filter_size_map), int(ekf_inited), C.byref(n))
+        return n.value
+
+    def get_target(self):
+        n = lib().orc_target_size(self._h)
+        out = np.zeros((n, 3), np.float32)
+        if n:
+            lib().orc_get_target(self._h, out.ctypes.data)
+        return out
+
+    @property
+    def target_voxels(self):
+        return lib().orc_target_voxels(self._h)
 
     def enable_trace(self, max_records=256):
         self._trace = np.zeros((max_records, 43))

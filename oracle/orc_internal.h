@@ -23,6 +23,7 @@ typedef struct orc_ivox {
 typedef struct orc_distpt_buf { void *data; size_t bytes; } orc_distpt_buf;
 
 struct orc_gauss_state;
+struct orc_lru_state;
 
 typedef struct oracle {
   orc_config cfg;
@@ -41,6 +42,9 @@ typedef struct oracle {
   double *trace;
   int trace_max, trace_n;
   struct orc_gauss_state *gauss;
+  struct orc_lru_state *lru;   /* sliding-map state (orc_lru.c) */
+  int *nn;                     /* [n_src][5] target indices of the last matching call, -1 = none */
+  long nn_cap;
 } oracle;
 
 void orc_vhash_init(orc_vhash *h, long expected);
@@ -51,6 +55,8 @@ void orc_ivox_key(const oracle *o, const float p[3], int key[3]);
 int orc_ivox_knn(const oracle *o, const float q[3], int *idx_out, float *d2_out, orc_distpt_buf *buf);
 int orc_esti_plane(const float *pts, int n, int K, int min_pts, float threshold, float plane[4]);
 void orc_prepare_model(oracle *o);
+void orc_lru_free(oracle *o);
+void orc_lru_reset(oracle *o);
 
 /* orc_models_gauss.c: GICP / VGICP / NDT residual models */
 double orc_gauss_linearize(oracle *o, const double T[16], double *H, double *b);

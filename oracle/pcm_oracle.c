@@ -46,6 +46,7 @@ void orc_default_config(orc_config *c) {
   c->k_correspondences = 20;            /* fast_gicp_impl.hpp:16 */
   c->regularization = ORC_REG_PLANE;    /* fast_gicp_impl.hpp:20 */
   c->num_threads = 0;
+  c->map_capacity = 1000000;            /* ivox3d.h:57 */
 }
 
 static int orc_threads(const oracle *o) {
@@ -454,6 +455,7 @@ int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int con
   for (int a = 0; a < 3; a++) offt[a] = (float)s->off_T[a];
   const long n = o->src.n;
   const int K = o->cfg.knn;
+  if (o->nn_cap < n) { free(o->nn); o->nn = (int *)malloc(sizeof(int) * 5 * (size_t)(n > 0 ? n : 1)); o->nn_cap = n; }
   double acc[92];
   memset(acc, 0, sizeof(acc));
   orc_distpt_buf buf = {0, 0};
@@ -469,6 +471,7 @@ int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int con
     int sel;
     if (converge) {
       int m = orc_ivox_knn(o, q, idx, NULL, &buf);
+      for (int j = 0; j < 5; j++) o->nn[i * 5 + j] = j < m ? idx[j] : -1;   /* nearest_points_[i] */
       sel = m >= o->cfg.min_knn;
       if (sel) {
         for (int j = 0; j < m; j++) for (int a = 0; a < 3; a++) near[j * 3 + a] = o->tgt.xyz[3 * (long)idx[j] + a];
@@ -662,6 +665,8 @@ void orc_destroy(void *h) {
   ivox_free(&o->tgt_ivox);
   free(o->plane);
   free(o->selected);
+  free(o->nn);
+  orc_lru_free(o);
   orc_gauss_free(o);
   free(o);
 }
@@ -670,6 +675,7 @@ int orc_set_target(void *h, const float *xyz, long n, long stride) {
   oracle *o = (oracle *)h;
   cloud_set(&o->tgt, xyz, n, stride);
   o->tgt_ivox.valid = 0;
+  orc_lru_reset(o);
   orc_gauss_invalidate(o, 1);
   return 0;
 }
@@ -686,6 +692,7 @@ void orc_swap_source_and_target(void *h) {
   oracle *o = (oracle *)h;
   orc_cloud t = o->src; o->src = o->tgt; o->tgt = t;
   o->tgt_ivox.valid = 0;
+  orc_lru_reset(o);
   orc_gauss_swap(o);
 }
 

@@ -44,6 +44,7 @@ typedef struct orc_config {
   int k_correspondences;      /* fast_gicp_impl.hpp:16 20 */
   int regularization;         /* fast_gicp_impl.hpp:20 PLANE */
   int num_threads;
+  long map_capacity;          /* ivox3d.h:57 capacity_ 1000000 (0 = unlimited) */
 } orc_config;
 
 typedef struct orc_result {
@@ -87,6 +88,15 @@ typedef struct orc_lio_state {
  * (5-NN + plane fit); converge == 0: re-use the planes of the previous call.  Returns 0, or -1
  * when there is no effective point (ekfom_data.valid = false, :657-661). */
 int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int converge, double HTH[144], double HTh[12], int *n_eff, double *sum_h2);
+
+/* IVox::AddPoints with the LRU voxel cache (jueying_lio/include/ivox3d/ivox3d.h:256-281) */
+int orc_target_insert(void *h, const float *xyz, long n, long stride_floats);
+/* LaserMapping::MapIncremental (jueying_lio/src/laser_mapping.cc:525-583) using the neighbours of the last
+ * orc_obs_model(converge != 0) call; returns the number of points inserted through n_added. */
+int orc_map_incremental(void *h, const orc_lio_state *s, double filter_size_map, int ekf_inited, long *n_added);
+long orc_target_size(void *h);
+long orc_target_voxels(void *h);
+void orc_get_target(void *h, float *out_xyz);
 
 /* building blocks exposed for unit pinning */
 void orc_test_so3_exp(const double omega[3], double R[9]);

@@ -13,7 +13,7 @@ SYMBOLS = [
     "pcm_abi_version", "pcm_default_config", "pcm_create", "pcm_destroy", "pcm_last_error",
     "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
     "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
-    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_obs_model", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
+    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
@@ -39,7 +39,7 @@ class PcmConfig(C.Structure):
                 ("min_knn", C.c_int32), ("max_range", C.c_float), ("plane_threshold", C.c_float),
                 ("max_corr_dist", C.c_float), ("k_correspondences", C.c_int32),
                 ("regularization", C.c_int32), ("sort_source", C.c_int32), ("flags", C.c_int32),
-                ("reserved", C.c_int32 * 6)]
+                ("map_capacity", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class PcmResult(C.Structure):
@@ -119,6 +119,9 @@ def load_library():
     L.pcm_compute_error.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.pcm_get_planes.argtypes = [vp, vp, sz]
     L.pcm_obs_model.argtypes = [vp, C.POINTER(PcmLioState), i32, i32, C.POINTER(PcmObsResult)]
+    L.pcm_target_insert.argtypes = [vp, vp, sz, sz, i32]
+    L.pcm_map_incremental.argtypes = [vp, C.POINTER(PcmLioState), C.c_float, i32, C.POINTER(sz)]
+    L.pcm_get_target.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.pcm_align_batch.argtypes = [C.POINTER(vp), i32, vp, vp, vp]
     L.pcm_set_profiling.argtypes = [vp, i32]
     L.pcm_debug_phase_cycles.argtypes = [vp, vp]

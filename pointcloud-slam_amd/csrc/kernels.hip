@@ -484,6 +484,23 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
       }
     }
     if (!use_lds && search) knn_global<STATS>(tg, q, cx, cy, cz, kp.num_neighbors, kp.max_range_sq, best, n_cand, n_probe);
+    if constexpr (LIO) {   // nearest_points_[i] for MapIncremental: indices into the map's point array, nearest first
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          uint32_t gi = ~0u;
+          if (j < best.m) {
+            gi = best.i[j];
+            if (use_lds) {
+              int b = 0;
+              while (b + 1 < s_bbox[6] && s_boff[b + 1] <= gi) b++;
+              gi = s_bps[b] + (gi - s_boff[b]);
+            }
+          }
+          *(PCM_GLOBAL uint32_t*)(d.nn + (size_t)i * K + j) = gi;
+        }
+      }
+    }
     PCM_STAMP(4)   // 27-cell / 5-NN search
 
     // ---- plane fit on the <= 5 neighbours  (laser_mapping.cc:619-623) -----------------------------

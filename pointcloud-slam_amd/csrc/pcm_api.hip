@@ -150,7 +150,7 @@ int set_cloud(pcm_ctx* c, Cloud* cl, const void* points, size_t n, size_t stride
   }
   cl->n = n;
   cl->tag = tag;
-  int rc = load_points_to_device(c->stream, points, n, stride, memory, cl->d_pts, &c->err);
+  int rc = load_points_to_device(c->stream, points, n, stride, memory, 0u, cl->d_pts, &c->err);
   if (rc != PCM_OK) return rc;
   HIPCK(c, hipStreamSynchronize(c->stream));  // the caller may free/reuse its buffer on return
   return PCM_OK;
@@ -163,14 +163,17 @@ int prepare(pcm_ctx* c) {
   const int mode = coord_mode_for(c->cfg.model);
   const bool gauss = is_ndt(c->cfg.model);
   if (!c->map.valid || c->map.res != c->cfg.voxel_resolution || c->map.coord_mode != mode || (gauss && !c->map.gvox)) {
-    int rc = build_target_map(c->stream, c->tgt.d_pts, (uint32_t)c->tgt.n, c->cfg.voxel_resolution, mode, gauss, &c->map, &c->err);
+    uint32_t n_log = (uint32_t)c->tgt.n;
+    int rc = build_target_map(c->stream, c->tgt.d_pts, &n_log, c->cfg.voxel_resolution, mode, gauss, (uint32_t)std::max(0, c->cfg.map_capacity), &c->map, &c->err);
+    c->tgt.n = n_log;   // LRU eviction compacts the point log
     if (rc != PCM_OK) return rc;
     c->stats.target_voxels = c->map.num_voxels;
     c->stats.target_slots = c->map.cap;
   }
   if (c->cfg.model == PCM_MODEL_NDT_D2D && (!c->srcmap.valid || c->srcmap.res != c->cfg.voxel_resolution)) {
     // D2D: the source elements are the source-voxel distributions (ndt_cuda.cu:120-129,156-158)
-    int rc = build_target_map(c->stream, c->src.d_pts, (uint32_t)c->src.n, c->cfg.voxel_resolution, mode, true, &c->srcmap, &c->err);
+    uint32_t n_src = (uint32_t)c->src.n;
+    int rc = build_target_map(c->stream, c->src.d_pts, &n_src, c->cfg.voxel_resolution, mode, true, 0u, &c->srcmap, &c->err);
     if (rc != PCM_OK) return rc;
   }
   if (gauss) {
@@ -192,6 +195,12 @@ int prepare(pcm_ctx* c) {
     HIPCK(c, hipMalloc(&c->counter, sizeof(unsigned int)));
     HIPCK(c, hipMemsetAsync(c->counter, 0, sizeof(unsigned int), c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+  }
+  if (c->nn_cap < c->src.n) {
+    if (c->nn) hipFree(c->nn);
+    c->nn = nullptr; c->nn_cap = 0;
+    HIPCK(c, hipMalloc(&c->nn, sizeof(uint32_t) * 5 * c->src.n));
+    c->nn_cap = c->src.n;
   }
   if (c->planes_cap < c->src.n) {
     if (c->planes) hipFree(c->planes);
@@ -236,6 +245,7 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->src.gvox = c->srcmap.gvox;
   d->src.num_points = (uint32_t)num_elements(c);
   d->corr = c->corr;
+  d->nn = c->nn;
   d->planes = c->planes;
   d->partials = partials;
   d->counter = c->counter;
@@ -476,6 +486,7 @@ void pcm_default_config(pcm_config* cfg) {
   cfg->k_correspondences = 20;
   cfg->regularization = PCM_REG_PLANE;
   cfg->sort_source = 1;
+  cfg->map_capacity = 1000000;   // IVox Options::capacity_  ivox3d.h:57
 }
 
 pcm_ctx* pcm_create(int device, const pcm_config* cfg) {
@@ -512,6 +523,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->corr) hipFree(c->corr);
     if (c->planes) hipFree(c->planes);
     if (c->counter) hipFree(c->counter);
+    if (c->nn) hipFree(c->nn);
     free_ws(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   }
@@ -554,6 +566,8 @@ int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   if (tag != 0 && tag == c->tgt.tag && c->tgt.n == n) return PCM_OK;  // `if (target_ == cloud) return;`  fast_gicp_impl.hpp:83-85
   int rc = set_cloud(c, &c->tgt, points, n, stride_bytes, memory, tag, false);
   c->map.valid = false;
+  c->next_seq = (uint32_t)n;
+  c->lio_planes_valid = false;
   return rc;
 }
 
@@ -729,6 +743,82 @@ int pcm_obs_model(pcm_ctx* c, const pcm_lio_state* s, int extrinsic_est_en, int 
   out->valid = out->n_eff >= 1 ? 1 : 0;
   c->stats.linearize_launches += 1;
   c->stats.point_passes += n;
+  return PCM_OK;
+}
+
+namespace {
+// grow the target point log to hold `need` points (keeps the content)
+int reserve_target(pcm_ctx* c, size_t need) {
+  if (need <= c->tgt.cap && !c->tgt.borrowed) return PCM_OK;
+  const size_t cap = std::max(need, c->tgt.cap + c->tgt.cap / 2 + 1024);
+  float4* nb = nullptr;
+  HIPCK(c, hipMalloc(&nb, sizeof(float4) * cap));
+  if (c->tgt.n) HIPCK(c, hipMemcpyAsync(nb, c->tgt.d_pts, sizeof(float4) * c->tgt.n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  const size_t n = c->tgt.n;
+  const uint64_t tag = c->tgt.tag;
+  c->tgt.drop_buffer();
+  c->tgt.d_pts = nb; c->tgt.cap = cap; c->tgt.n = n; c->tgt.tag = tag;
+  return PCM_OK;
+}
+}  // namespace
+
+int pcm_target_insert(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes, int memory) {
+  CHECK_CTX(c);
+  if (!points && n) { c->err = "null point buffer"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (stride_bytes < 3 * sizeof(float) || (stride_bytes % sizeof(float)) != 0) { c->err = "stride must be a multiple of 4 and >= 12 bytes"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (n == 0) return PCM_OK;
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = reserve_target(c, c->tgt.n + n);
+  if (rc != PCM_OK) return rc;
+  rc = load_points_to_device(c->stream, points, n, stride_bytes, memory, c->next_seq, c->tgt.d_pts + c->tgt.n, &c->err);
+  if (rc != PCM_OK) return rc;
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  c->tgt.n += n;
+  c->next_seq += (uint32_t)n;
+  c->tgt.tag = 0;
+  c->map.valid = false;
+  return PCM_OK;
+}
+
+int pcm_map_incremental(pcm_ctx* c, const pcm_lio_state* s, float filter_size_map, int ekf_inited, size_t* num_added) {
+  CHECK_CTX(c);
+  if (!s) return PCM_ERR_INVALID_ARGUMENT;
+  if (c->src.n == 0) { c->err = "pcm_map_incremental without a source scan"; return PCM_ERR_NO_INPUT; }
+  HIPCK(c, hipSetDevice(c->device));
+  const uint32_t n = (uint32_t)c->src.n;
+  int rc = reserve_target(c, c->tgt.n + n);
+  if (rc != PCM_OK) return rc;
+  const bool have_nn = c->lio_planes_valid && c->nn != nullptr && c->map.valid && ekf_inited;
+  LioStateD L;
+  for (int a = 0; a < 4; a++) { L.rot[a] = s->rot[a]; L.off_R[a] = s->off_R[a]; }
+  for (int a = 0; a < 3; a++) { L.pos[a] = s->pos[a]; L.off_T[a] = s->off_T[a]; }
+  const float4* scan = (c->cfg.sort_source && c->src_sorted) ? c->src_order : c->src.d_pts;
+  uint32_t added = 0;
+  rc = map_incremental_device(c->stream, scan, n, L, filter_size_map, have_nn ? c->nn : nullptr, have_nn ? c->map.pts : nullptr, c->next_seq,
+                              c->tgt.d_pts + c->tgt.n, &added, &c->err);
+  if (rc != PCM_OK) return rc;
+  c->tgt.n += added;
+  c->next_seq += added;
+  c->tgt.tag = 0;
+  if (added) c->map.valid = false;
+  if (num_added) *num_added = added;
+  return PCM_OK;
+}
+
+int pcm_get_target(pcm_ctx* c, float* out_xyz, size_t capacity_points, size_t* n) {
+  CHECK_CTX(c);
+  if (!n) return PCM_ERR_INVALID_ARGUMENT;
+  if (c->tgt.n && c->cfg.map_capacity > 0 && !c->map.valid && c->src.n) {
+    int rc = prepare(c);   // apply a pending LRU eviction so the log is the current map
+    if (rc != PCM_OK) return rc;
+  }
+  *n = c->tgt.n;
+  if (!out_xyz) return PCM_OK;
+  if (capacity_points < c->tgt.n) { c->err = "pcm_get_target: buffer too small"; return PCM_ERR_INVALID_ARGUMENT; }
+  std::vector<float4> tmp(c->tgt.n);
+  HIPCK(c, hipMemcpy(tmp.data(), c->tgt.d_pts, sizeof(float4) * c->tgt.n, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < c->tgt.n; i++) { out_xyz[3 * i] = tmp[i].x; out_xyz[3 * i + 1] = tmp[i].y; out_xyz[3 * i + 2] = tmp[i].z; }
   return PCM_OK;
 }
 

@@ -142,6 +142,7 @@ struct PairDesc {
   SourceView src;
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
   LioPose lio;          // LIO measurement model only
+  uint32_t* nn;         // LIO: [N][5] neighbour indices into tgt.pts (~0u: none) from the last matching call
   int32_t* corr;        // NDT: [elements][offsets] matched target voxel (or -1) of the last linearize
   double* partials;     // [workgroups of the round][kPartialStride]
   unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)

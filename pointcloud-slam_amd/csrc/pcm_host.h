@@ -52,8 +52,9 @@ struct TargetMap {   // layout: pcm_device.h
   }
 };
 
-int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, bool want_gauss, TargetMap* map, std::string* err);
-int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, float4* d_out, std::string* err);
+int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
+                     std::string* err);
+int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, uint32_t seq0, float4* d_out, std::string* err);
 // batched scan re-ordering (voxel_hash.hip)
 struct SortJob {
   const float4* src;   // scan in input order
@@ -69,6 +70,10 @@ struct SortScratch {
   void* tmp = nullptr;
   size_t cap = 0, tmp_bytes = 0;
 };
+// MapIncremental on the device (voxel_hash.hip)
+struct LioStateD { double rot[4], pos[3], off_R[4], off_T[3]; };
+int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, const LioStateD& s, float filter_size_map, const uint32_t* nn, const float4* map_pts,
+                           uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err);
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
                          SortScratch* ws, std::string* err);
 
@@ -110,6 +115,9 @@ struct pcm_ctx {
   std::string err;
   pcm_stats stats{};
   uint64_t phase_cycles[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // diagnostic (profiling bit2)
+  uint32_t* nn = nullptr;          // LIO: the <= 5 neighbours (indices into map.pts) of every scan point from the last matching call
+  size_t nn_cap = 0;
+  uint32_t next_seq = 0;           // next insertion sequence number of the target point log
   bool lio_planes_valid = false;   // planes of the last pcm_obs_model(rematch=1) belong to the current scan
   void* ws = nullptr;   // batch workspace owned by this context (pcm_api.hip)
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters

@@ -22,12 +22,13 @@
 
 namespace pcm {
 
-// strided xyz records -> compact float4 (w = 1)
-__global__ void k_load_points(const char* __restrict__ base, size_t stride, uint32_t n, float4* __restrict__ out) {
+// strided xyz records -> compact float4; .w = insertion sequence number (raw uint bits): the
+// "last touched" order of the sliding map's LRU eviction is derived from it
+__global__ void k_load_points(const char* __restrict__ base, size_t stride, uint32_t n, uint32_t seq0, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = reinterpret_cast<const float*>(base + (size_t)i * stride);
-  out[i] = make_float4(p[0], p[1], p[2], 1.0f);
+  out[i] = make_float4(p[0], p[1], p[2], __uint_as_float(seq0 + i));
 }
 
 __device__ inline int voxel_coord(float v, float res, float inv_res, int mode) {
@@ -139,6 +140,35 @@ __global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* _
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------
+// Sliding-map eviction: IVox keeps its voxels in a least-recently-touched list and
+// drops the tail when a new voxel brings the count to `capacity`
+// (/root/reference/src/jueying_lio/include/ivox3d/ivox3d.h:256-281).  A voxel's place
+// in that list is decided by its LAST insertion, i.e. by the largest insertion
+// sequence number among its points; so the survivors of a batch are the
+// (capacity - 1) voxels with the largest such number.  (Difference from the
+// sequential list: a voxel evicted and re-created inside one batch would restart
+// empty in the reference; here it keeps its points.)
+// ---------------------------------------------------------------------------
+__global__ void k_voxel_last(const float4* __restrict__ log, const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vrank,
+                             uint32_t n, uint32_t* __restrict__ vlast) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  atomicMax(&vlast[vrank[i] + vflag[i] - 1u], __float_as_uint(log[idx_s[i]].w));
+}
+
+__global__ void k_mark_alive(const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vrank, const uint32_t* __restrict__ vlast,
+                             uint32_t cutoff, uint32_t n, uint32_t* __restrict__ alive) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  alive[idx_s[i]] = vlast[vrank[i] + vflag[i] - 1u] >= cutoff ? 1u : 0u;
+}
+
+__global__ void k_compact_log(const float4* __restrict__ in, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ pos, uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && alive[i]) out[pos[i]] = in[i];
+}
+
+// ---------------------------------------------------------------------------
 // Gaussian voxel statistics of the NDT models:
 //   sums .......... gaussian_voxelmap.cu:122-148 (x and x x^T per voxel)
 //   mean / cov .... gaussian_voxelmap.cu:178-198  cov = (sum x x^T - mean * sum x^T) / n
@@ -248,8 +278,10 @@ __global__ void k_gauss_voxels(const float4* __restrict__ pts, const uint32_t* _
 }
 
 // Build the voxel hash of `cloud` into `map`.  One host sync (voxel / brick counts -> array sizes).
-int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float res, int coord_mode, bool want_gauss, TargetMap* map, std::string* err) {
+int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
+                     std::string* err) {
   map->release();
+  uint32_t n = *n_inout;
   if (n == 0) { *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
   uint64_t *keys = nullptr, *keys_s = nullptr;
   uint32_t *idx = nullptr, *idx_s = nullptr, *vflag = nullptr, *vrank = nullptr;
@@ -291,6 +323,54 @@ int build_target_map(hipStream_t stream, const float4* d_pts, uint32_t n, float 
     if (h_flags[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
     const uint32_t nvox = h_last[0] + h_last[1];
     const uint32_t nbricks = (uint32_t)h_flags[1];
+    if (capacity_voxels > 1 && nvox > capacity_voxels - 1) {
+      // ---- LRU eviction: keep the (capacity - 1) most recently touched voxels, compact the log, rebuild ----
+      const uint32_t keep = capacity_voxels - 1;
+      uint32_t *vlast = nullptr, *vsorted = nullptr, *alive = nullptr, *pos = nullptr;
+      float4* tmp_log = nullptr;
+      void* tmp3 = nullptr;
+      size_t tmp3_bytes = 0, tmp4_bytes = 0;
+      void* tmp4 = nullptr;
+      uint32_t cutoff = 0, h_tail[2] = {0, 0};
+      int rc2 = PCM_OK;
+#define CK2(x)                                                                   \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc2 = PCM_ERR_HIP; goto evict_done; } \
+  } while (0)
+      CK2(hipMalloc(&vlast, sizeof(uint32_t) * nvox));
+      CK2(hipMalloc(&vsorted, sizeof(uint32_t) * nvox));
+      CK2(hipMalloc(&alive, sizeof(uint32_t) * n));
+      CK2(hipMalloc(&pos, sizeof(uint32_t) * n));
+      CK2(hipMalloc(&tmp_log, sizeof(float4) * n));
+      CK2(hipMemsetAsync(vlast, 0, sizeof(uint32_t) * nvox, stream));
+      k_voxel_last<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, vflag, vrank, n, vlast);
+      CK2(hipGetLastError());
+      CK2(rocprim::radix_sort_keys(nullptr, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
+      CK2(hipMalloc(&tmp3, tmp3_bytes));
+      CK2(rocprim::radix_sort_keys(tmp3, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
+      CK2(hipMemcpyAsync(&cutoff, vsorted + (nvox - keep), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CK2(hipStreamSynchronize(stream));
+      k_mark_alive<<<cdiv(n, 256), 256, 0, stream>>>(idx_s, vflag, vrank, vlast, cutoff, n, alive);
+      CK2(hipGetLastError());
+      CK2(rocprim::exclusive_scan(nullptr, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+      CK2(hipMalloc(&tmp4, tmp4_bytes));
+      CK2(rocprim::exclusive_scan(tmp4, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+      k_compact_log<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, alive, pos, n, tmp_log);
+      CK2(hipGetLastError());
+      CK2(hipMemcpyAsync(&h_tail[0], pos + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CK2(hipMemcpyAsync(&h_tail[1], alive + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CK2(hipStreamSynchronize(stream));
+      CK2(hipMemcpyAsync(d_pts, tmp_log, sizeof(float4) * (size_t)(h_tail[0] + h_tail[1]), hipMemcpyDeviceToDevice, stream));
+      CK2(hipStreamSynchronize(stream));
+      *n_inout = h_tail[0] + h_tail[1];
+    evict_done:
+      hipFree(vlast); hipFree(vsorted); hipFree(alive); hipFree(pos); hipFree(tmp_log); hipFree(tmp3); hipFree(tmp4);
+#undef CK2
+      hipFree(keys); hipFree(keys_s); hipFree(idx); hipFree(idx_s); hipFree(vflag); hipFree(vrank); hipFree(d_flags); hipFree(tmp); hipFree(tmp2);
+      if (rc2 != PCM_OK) return rc2;
+      return build_target_map(stream, d_pts, n_inout, res, coord_mode, want_gauss, 0u, map, err);   // now within capacity
+    }
     uint32_t cap = 1024;
     while (cap < 4ull * nbricks) cap <<= 1;
     if (cap > kMaxBrickSlots) { *err = "too many occupied bricks for the 22-bit voxel tag"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
@@ -418,11 +498,110 @@ done:
 #undef CK
 }
 
-int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, float4* d_out, std::string* err) {
+// ---------------------------------------------------------------------------
+// LaserMapping::MapIncremental (/root/reference/src/jueying_lio/src/laser_mapping.cc:525-583)
+// ---------------------------------------------------------------------------
+__device__ inline void qrot_d(const double* q, const double* v, double* r) {   // Eigen _transformVector, (x,y,z,w)
+  double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+  for (int a = 0; a < 3; a++) r[a] = v[a] + q[3] * uv[a] + c[a];
+}
+
+// flag[i]: 0 = not added, 1 = points_to_add, 2 = point_no_need_downsample; world[i] = PointBodyToWorld(scan[i])
+__global__ void k_map_filter(const float4* __restrict__ scan, uint32_t n, LioStateD s, float fs, const uint32_t* __restrict__ nn, const float4* __restrict__ map_pts,
+                             float4* __restrict__ world, uint32_t* __restrict__ f1, uint32_t* __restrict__ f2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 pb = scan[i];
+  // p_global = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos   in double   laser_mapping.cc:855-864
+  const double vb[3] = {(double)pb.x, (double)pb.y, (double)pb.z};
+  double v1[3], v2[3];
+  qrot_d(s.off_R, vb, v1);
+  for (int a = 0; a < 3; a++) v1[a] += s.off_T[a];
+  qrot_d(s.rot, v1, v2);
+  const float pw[3] = {(float)(v2[0] + s.pos[0]), (float)(v2[1] + s.pos[1]), (float)(v2[2] + s.pos[2])};
+  world[i] = make_float4(pw[0], pw[1], pw[2], 0.f);
+  uint32_t flag = 1;
+  if (nn != nullptr && nn[(size_t)i * 5] != ~0u) {   // !nearest_points_[i].empty() && flg_EKF_inited_
+    float center[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) center[a] = (floorf(pw[a] / fs) + 0.5f) * fs;   // :547-548
+    const float4 n0 = map_pts[nn[(size_t)i * 5]];
+    const double half = 0.5 * (double)fs;
+    if ((double)fabsf(n0.x - center[0]) > half && (double)fabsf(n0.y - center[1]) > half && (double)fabsf(n0.z - center[2]) > half) {
+      flag = 2;                                                                  // :552-557
+    } else {
+      const float dx = pw[0] - center[0], dy = pw[1] - center[1], dz = pw[2] - center[2];
+      const float dist = dx * dx + dy * dy + dz * dz;
+      bool need_add = true;
+      if (nn[(size_t)i * 5 + 4] != ~0u) {                                       // points_near.size() >= NUM_MATCH_POINTS
+        for (int k = 0; k < 5; k++) {
+          const float4 q = map_pts[nn[(size_t)i * 5 + k]];
+          const float ex = q.x - center[0], ey = q.y - center[1], ez = q.z - center[2];
+          if ((double)(ex * ex + ey * ey + ez * ez) < (double)dist + 1e-6) { need_add = false; break; }   // :563-566
+        }
+      }
+      flag = need_add ? 1u : 0u;
+    }
+  }
+  f1[i] = flag == 1 ? 1u : 0u;
+  f2[i] = flag == 2 ? 1u : 0u;
+}
+
+__global__ void k_map_append(const float4* __restrict__ world, const uint32_t* __restrict__ f1, const uint32_t* __restrict__ f2, const uint32_t* __restrict__ p1,
+                             const uint32_t* __restrict__ p2, uint32_t n, uint32_t n1, uint32_t seq0, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (f1[i]) { float4 v = world[i]; v.w = __uint_as_float(seq0 + p1[i]); out[p1[i]] = v; }                 // ivox_->AddPoints(points_to_add)
+  if (f2[i]) { float4 v = world[i]; v.w = __uint_as_float(seq0 + n1 + p2[i]); out[n1 + p2[i]] = v; }       // then point_no_need_downsample
+}
+
+int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, const LioStateD& s, float filter_size_map, const uint32_t* nn, const float4* map_pts,
+                           uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err) {
+  float4* world = nullptr;
+  uint32_t* buf = nullptr;   // f1, f2, p1, p2
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  int rc = PCM_OK;
+  uint32_t tails[4] = {0, 0, 0, 0};
+#define CK(x)                                                                    \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
+  } while (0)
+  CK(hipMalloc(&world, sizeof(float4) * n));
+  CK(hipMalloc(&buf, sizeof(uint32_t) * 4 * (size_t)n));
+  {
+    uint32_t *f1 = buf, *f2 = buf + n, *p1 = buf + 2 * (size_t)n, *p2 = buf + 3 * (size_t)n;
+    k_map_filter<<<cdiv(n, 256), 256, 0, stream>>>(scan, n, s, filter_size_map, nn, map_pts, world, f1, f2);
+    CK(hipGetLastError());
+    CK(rocprim::exclusive_scan(nullptr, tmp_bytes, f1, p1, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    CK(hipMalloc(&tmp, tmp_bytes));
+    CK(rocprim::exclusive_scan(tmp, tmp_bytes, f1, p1, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    CK(rocprim::exclusive_scan(tmp, tmp_bytes, f2, p2, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    CK(hipMemcpyAsync(&tails[0], f1 + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&tails[1], p1 + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&tails[2], f2 + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&tails[3], p2 + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    const uint32_t n1 = tails[0] + tails[1], n2 = tails[2] + tails[3];
+    k_map_append<<<cdiv(n, 256), 256, 0, stream>>>(world, f1, f2, p1, p2, n, n1, seq0, out_append);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(stream));
+    *num_added = n1 + n2;
+  }
+done:
+  hipFree(world); hipFree(buf); hipFree(tmp);
+  return rc;
+#undef CK
+}
+
+int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, uint32_t seq0, float4* d_out, std::string* err) {
   if (n == 0) return PCM_OK;
   hipError_t e;
   if (memory == PCM_MEM_DEVICE) {
-    k_load_points<<<cdiv((uint32_t)n, 256), 256, 0, stream>>>(static_cast<const char*>(points), stride, (uint32_t)n, d_out);
+    k_load_points<<<cdiv((uint32_t)n, 256), 256, 0, stream>>>(static_cast<const char*>(points), stride, (uint32_t)n, seq0, d_out);
     e = hipGetLastError();
     if (e != hipSuccess) { *err = std::string("k_load_points: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
     return PCM_OK;
@@ -430,7 +609,7 @@ int load_points_to_device(hipStream_t stream, const void* points, size_t n, size
   // host records: copy the 12-byte xyz prefix of every record into 16-byte rows, then normalise w
   e = hipMemcpy2DAsync(d_out, sizeof(float4), points, stride, 3 * sizeof(float), n, hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) { *err = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
-  k_load_points<<<cdiv((uint32_t)n, 256), 256, 0, stream>>>(reinterpret_cast<const char*>(d_out), sizeof(float4), (uint32_t)n, d_out);
+  k_load_points<<<cdiv((uint32_t)n, 256), 256, 0, stream>>>(reinterpret_cast<const char*>(d_out), sizeof(float4), (uint32_t)n, seq0, d_out);
   e = hipGetLastError();
   if (e != hipSuccess) { *err = std::string("k_load_points: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
   return PCM_OK;

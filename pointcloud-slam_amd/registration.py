@@ -158,6 +158,28 @@ class Registration:
         self._check(self._L.pcm_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), C.byref(out)))
         return np.array(out.HTH[:]).reshape(12, 12), np.array(out.HTh[:]), out.n_eff, out.sum_h2, bool(out.valid)
 
+    def target_insert(self, cloud):
+        """IVox::AddPoints: append points to the sliding submap (LRU beyond map_capacity voxels)."""
+        ptr, n, stride, mem, keep = _points(cloud)
+        self._check(self._L.pcm_target_insert(self._h, ptr, n, stride, mem))
+
+    def map_incremental(self, rot_xyzw, pos, off_R_xyzw, off_T, filter_size_map: float, ekf_inited: bool = True) -> int:
+        """LaserMapping::MapIncremental with the add-filter; returns the number of points inserted."""
+        st = capi.PcmLioState()
+        st.rot[:] = list(rot_xyzw); st.pos[:] = list(pos); st.off_R[:] = list(off_R_xyzw); st.off_T[:] = list(off_T)
+        n = C.c_size_t()
+        self._check(self._L.pcm_map_incremental(self._h, C.byref(st), C.c_float(filter_size_map), int(ekf_inited), C.byref(n)))
+        return n.value
+
+    def get_target(self) -> np.ndarray:
+        """(M,3) current target points in insertion order."""
+        n = C.c_size_t()
+        self._check(self._L.pcm_get_target(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3), np.float32)
+        if n.value:
+            self._check(self._L.pcm_get_target(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
     def get_planes(self, n: int) -> np.ndarray:
         """(n,4) planes fitted by the last evaluate_cost (NaN row = point not selected)."""
         out = np.zeros((n, 4), np.float32)

@@ -62,3 +62,54 @@ def test_obs_model_errors(pcm, synth):
     g.set_input_source(far)
     H, h, n, s2, valid = g.obs_model(*st, False, True)
     assert n == 0 and not valid                 # "No Effective Points!" laser_mapping.cc:657-661
+
+
+def test_sliding_map_add_filter_matches_oracle(pcm, synth):
+    """Three LIO frames: match -> MapIncremental (add-filter against the matched neighbours) ->
+    rebuilt voxel hash; the map content must equal the oracle's point for point."""
+    from oracle import Oracle
+    scene = synth.scene_for_points(1234, 60000, 8.0)
+    submap = synth.sample_submap(scene, 60000, 4321)
+    o = Oracle("P2PLANE", "GN", voxel_resolution=0.5, num_neighbors=27)
+    g = pcm.P2PlaneRegistration(0, voxel_resolution=0.5, num_neighbors=27, sort_source=0)
+    o.set_input_target(submap); g.set_input_target(submap)
+    T = synth.sensor_pose(scene, 77)
+    for f in range(3):
+        Tf = T.copy(); Tf[:3, 3] += Tf[:3, 0] * 0.6 * f          # the sensor advances 0.6 m per frame
+        scan, _ = synth.livox_scan(scene, Tf, 4000, 555 + f)
+        st = _state(Tf)
+        o.set_input_source(scan); g.set_input_source(scan)
+        H0, h0, n0, s0 = o.obs_model(*st, False, True)
+        H1, h1, n1, s1, valid = g.obs_model(*st, False, True)
+        assert n0 == n1 and rel_err(H1, H0) < HB_RTOL
+        a0 = o.map_incremental(*st, 0.5, True)
+        a1 = g.map_incremental(*st, 0.5, True)
+        assert a0 == a1 and 0 < a1 < len(scan)                   # the filter keeps some points and rejects some
+        assert np.array_equal(g.get_target(), o.get_target())
+    # first frame of a run (flg_EKF_inited_ false): every point is added
+    scan, _ = synth.livox_scan(scene, T, 1000, 999)
+    o.set_input_source(scan); g.set_input_source(scan)
+    assert o.map_incremental(*_state(T), 0.5, False) == g.map_incremental(*_state(T), 0.5, False) == 1000
+    assert np.array_equal(g.get_target(), o.get_target())
+
+
+def test_sliding_map_lru_eviction_matches_oracle(pcm, synth):
+    """IVox LRU (ivox3d.h:256-281): inserting new territory beyond the capacity drops the
+    least-recently-touched voxels; a later touch protects a voxel."""
+    from oracle import Oracle
+    rng = np.random.default_rng(3)
+    base = rng.uniform(0, 20, (3000, 3)).astype(np.float32)          # ~2500 voxels of 0.5 m... sparse cloud
+    cap = 4000
+    o = Oracle("P2PLANE", "GN", voxel_resolution=0.5, num_neighbors=27, map_capacity=cap)
+    g = pcm.P2PlaneRegistration(0, voxel_resolution=0.5, num_neighbors=27, map_capacity=cap)
+    o.set_input_target(base); g.set_input_target(base)
+    g.set_input_source(base[:10]); o.set_input_source(base[:10])
+    for k in range(4):
+        touch = base[100 * k:100 * k + 50] + np.float32(0.01)         # re-touch some old voxels first ...
+        new = (rng.uniform(0, 20, (900, 3)) + [30 * (k + 1), 0, 0]).astype(np.float32)   # ... then new territory
+        for batch in (touch, new):
+            o.target_insert(batch); g.target_insert(batch)
+        got, want = g.get_target(), o.get_target()
+        assert o.target_voxels <= cap - 1
+        assert np.array_equal(got, want)
+    assert len(want) < 3000 + 4 * 950                                  # something was evicted
