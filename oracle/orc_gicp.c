@@ -1,0 +1,362 @@
+/*
+ * oracle/orc_gicp.c -- GICP and VGICP residual models of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ *
+ * What is restated here, and from where (paths relative to
+ * /root/reference/src/pointcloud_match/fast_gicp/include/fast_gicp/gicp):
+ *   covariance estimation ....... impl/fast_gicp_impl.hpp:239-298 (kNN k=20, XX^T/k, regularisation)
+ *   FastGICP correspondences ..... impl/fast_gicp_impl.hpp:114-152 (float transform, exact 1-NN, RCR^-1)
+ *   FastGICP linearize / error ... impl/fast_gicp_impl.hpp:154-237
+ *   VGICP voxel map .............. fast_vgicp_voxel.hpp:10-44,94-182 (ADDITIVE accumulation, floor(x/res-0.5))
+ *   FastVGICP correspondences .... impl/fast_vgicp_impl.hpp:72-124
+ *   FastVGICP linearize / error .. impl/fast_vgicp_impl.hpp:126-204
+ * The kd-tree (pcl::search::KdTree -> FLANN, not in the tree) returns the exact Euclidean k
+ * nearest neighbours; here the same set is found with a uniform grid and an exactness test per
+ * ring (verified against brute force in tests/test_oracle_kat.py).  JacobiSVD of the symmetric
+ * PSD covariance = its eigen-decomposition (cyclic Jacobi, orc_linalg.h).
+ */
+#include "orc_internal.h"
+
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- uniform grid for exact kNN ------------------------------------------------------------- */
+typedef struct orc_grid {
+  orc_vhash h;
+  int *start, *pts;
+  long ncell;
+  double cell;
+} orc_grid;
+
+static void grid_free(orc_grid *g) { orc_vhash_free(&g->h); free(g->start); free(g->pts); memset(g, 0, sizeof(*g)); }
+
+static inline void grid_key(const orc_grid *g, const float p[3], int k[3]) {
+  for (int a = 0; a < 3; a++) k[a] = (int)floor((double)p[a] / g->cell);
+}
+
+static void grid_build(orc_grid *g, const orc_cloud *c, double cell) {
+  grid_free(g);
+  g->cell = cell;
+  orc_vhash_init(&g->h, c->n);
+  int *pv = (int *)malloc(sizeof(int) * (size_t)(c->n + 1));
+  for (long i = 0; i < c->n; i++) { int k[3]; grid_key(g, c->xyz + 3 * i, k); pv[i] = orc_vhash_insert(&g->h, k[0], k[1], k[2]); }
+  g->ncell = g->h.count;
+  g->start = (int *)calloc((size_t)g->ncell + 1, sizeof(int));
+  g->pts = (int *)malloc(sizeof(int) * (size_t)(c->n + 1));
+  for (long i = 0; i < c->n; i++) g->start[pv[i] + 1]++;
+  for (long j = 0; j < g->ncell; j++) g->start[j + 1] += g->start[j];
+  int *fill = (int *)malloc(sizeof(int) * ((size_t)g->ncell + 1));
+  memcpy(fill, g->start, sizeof(int) * ((size_t)g->ncell + 1));
+  for (long i = 0; i < c->n; i++) g->pts[fill[pv[i]]++] = (int)i;
+  free(fill); free(pv);
+}
+
+/* exact k nearest neighbours of q (float squared distances like FLANN's L2_Simple<float>);
+ * out sorted ascending (distance, then index).  Returns the number found (< k only for tiny clouds). */
+static int grid_knn(const orc_grid *g, const orc_cloud *c, const float q[3], int k, double max_d2, int *idx, float *d2) {
+  int key[3], n = 0;
+  grid_key(g, q, key);
+  const int RMAX = 64;
+  for (int R = 0; R <= RMAX; R++) {
+    for (int dx = -R; dx <= R; dx++) for (int dy = -R; dy <= R; dy++) for (int dz = -R; dz <= R; dz++) {
+      const int m = abs(dx) > abs(dy) ? abs(dx) : abs(dy);
+      if ((m > abs(dz) ? m : abs(dz)) != R) continue;   /* shell only */
+      const int v = orc_vhash_find(&g->h, key[0] + dx, key[1] + dy, key[2] + dz);
+      if (v < 0) continue;
+      for (int s = g->start[v]; s < g->start[v + 1]; s++) {
+        const int pi = g->pts[s];
+        const float *p = c->xyz + 3 * (long)pi;
+        const float ex = p[0] - q[0], ey = p[1] - q[1], ez = p[2] - q[2];
+        const float dd = ex * ex + ey * ey + ez * ez;
+        /* insert into the sorted top-k (ties: lower index first) */
+        int pos = n < k ? n : k;
+        while (pos > 0 && (dd < d2[pos - 1] || (dd == d2[pos - 1] && pi < idx[pos - 1]))) pos--;
+        if (pos >= k) continue;
+        const int last = n < k ? n : k - 1;
+        for (int t = last; t > pos; t--) { d2[t] = d2[t - 1]; idx[t] = idx[t - 1]; }
+        d2[pos] = dd; idx[pos] = pi;
+        if (n < k) n++;
+      }
+    }
+    /* every unseen point is farther than R * cell from q: exact once the k-th distance is inside, or nothing within max_d2 remains */
+    const double reach = (double)R * g->cell;
+    if (n == k && (double)d2[k - 1] <= reach * reach) break;
+    if (reach * reach > max_d2) break;
+    if ((long)(2 * R + 1) * (2 * R + 1) * (2 * R + 1) > 8 * g->ncell + 27 && n >= (c->n < k ? (int)c->n : k)) break;   /* the whole cloud was visited */
+  }
+  return n;
+}
+
+/* ---- per-point covariances  fast_gicp_impl.hpp:239-298 --------------------------------------- */
+static void regularize(int method, const double cov[9], double out[9]) {
+  if (method == ORC_REG_NONE) { memcpy(out, cov, 9 * sizeof(double)); return; }
+  if (method == ORC_REG_FROBENIUS) {   /* :266-271 */
+    double C[9], Ci[9], N[9];
+    memcpy(C, cov, sizeof(C));
+    C[0] += 1e-3; C[4] += 1e-3; C[8] += 1e-3;
+    orc_inv3d(C, Ci);
+    double nrm = 0.0;
+    for (int a = 0; a < 9; a++) nrm += Ci[a] * Ci[a];
+    nrm = sqrt(nrm);
+    for (int a = 0; a < 9; a++) N[a] = Ci[a] / nrm;
+    orc_inv3d(N, out);
+    return;
+  }
+  double w[3], V[9], val[3];
+  orc_eig3_sym(cov, w, V);   /* ascending; singular values of the SVD are these, descending */
+  if (method == ORC_REG_PLANE) { val[0] = 1e-3; val[1] = 1.0; val[2] = 1.0; }                         /* (1, 1, 1e-3) on descending order */
+  else if (method == ORC_REG_MIN_EIG) { for (int k = 0; k < 3; k++) val[k] = w[k] > 1e-3 ? w[k] : 1e-3; }
+  else { for (int k = 0; k < 3; k++) { const double v = w[k] / w[2]; val[k] = v > 1e-3 ? v : 1e-3; } }   /* NORMALIZED_MIN_EIG */
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+    double s = 0.0;
+    for (int k = 0; k < 3; k++) s += V[a * 3 + k] * val[k] * V[b * 3 + k];
+    out[a * 3 + b] = s;
+  }
+}
+
+void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs /* 9 per point */) {
+  orc_grid g;
+  memset(&g, 0, sizeof(g));
+  grid_build(&g, c, o->cfg.voxel_resolution);
+  const int k = o->cfg.k_correspondences;
+#ifdef _OPENMP
+  const int nth = o->cfg.num_threads > 0 ? o->cfg.num_threads : omp_get_max_threads();
+#else
+  const int nth = 1;
+#endif
+#pragma omp parallel for num_threads(nth) schedule(dynamic, 64)
+  for (long i = 0; i < c->n; i++) {
+    int idx[64];
+    float d2[64];
+    const int m = grid_knn(&g, c, c->xyz + 3 * i, k, 1e300, idx, d2);
+    double mean[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < m; j++) for (int a = 0; a < 3; a++) mean[a] += (double)c->xyz[3 * (long)idx[j] + a];
+    for (int a = 0; a < 3; a++) mean[a] /= (double)k;              /* rowwise().mean() over k columns */
+    for (int j = 0; j < m; j++) {
+      double d[3];
+      for (int a = 0; a < 3; a++) d[a] = (double)c->xyz[3 * (long)idx[j] + a] - mean[a];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov[a * 3 + b] += d[a] * d[b];
+    }
+    for (int a = 0; a < 9; a++) cov[a] /= (double)k;
+    regularize(o->cfg.regularization, cov, covs + 9 * i);
+  }
+  grid_free(&g);
+}
+
+/* ---- model state ---------------------------------------------------------------------------- */
+typedef struct orc_vgvox { double mean[3], cov[9]; int n; } orc_vgvox;
+
+typedef struct orc_gicp_state {
+  double *src_cov, *tgt_cov;    /* 9 doubles per point */
+  long src_n, tgt_n;
+  orc_grid tgt_grid;            /* exact 1-NN of GICP */
+  int tgt_grid_valid;
+  int *corr;                    /* GICP: target index per source point; VGICP: voxel per (point, offset) */
+  double *maha;                 /* 9 doubles per correspondence */
+  long corr_cap;
+  /* VGICP voxel map */
+  orc_vhash vh;
+  orc_vgvox *vox;
+  long nvox;
+  int vmap_valid;
+} orc_gicp_state;
+
+static orc_gicp_state *st(oracle *o) {
+  if (!o->gicp) o->gicp = calloc(1, sizeof(orc_gicp_state));
+  return (orc_gicp_state *)o->gicp;
+}
+
+void orc_gicp_invalidate(oracle *o, int target) {
+  if (!o->gicp) return;
+  orc_gicp_state *s = (orc_gicp_state *)o->gicp;
+  if (target) { free(s->tgt_cov); s->tgt_cov = NULL; s->tgt_n = 0; s->tgt_grid_valid = 0; s->vmap_valid = 0; }
+  else { free(s->src_cov); s->src_cov = NULL; s->src_n = 0; }
+}
+
+void orc_gicp_swap(oracle *o) {
+  if (!o->gicp) return;
+  orc_gicp_state *s = (orc_gicp_state *)o->gicp;
+  double *t = s->src_cov; s->src_cov = s->tgt_cov; s->tgt_cov = t;
+  long n = s->src_n; s->src_n = s->tgt_n; s->tgt_n = n;
+  s->tgt_grid_valid = 0;
+  s->vmap_valid = 0;
+}
+
+void orc_gicp_free(oracle *o) {
+  if (!o->gicp) return;
+  orc_gicp_state *s = (orc_gicp_state *)o->gicp;
+  free(s->src_cov); free(s->tgt_cov); grid_free(&s->tgt_grid); free(s->corr); free(s->maha);
+  orc_vhash_free(&s->vh); free(s->vox);
+  free(s);
+  o->gicp = NULL;
+}
+
+/* GaussianVoxelMap::create_voxelmap (ADDITIVE)  fast_vgicp_voxel.hpp:129-156 */
+static void vgicp_build_voxelmap(oracle *o, orc_gicp_state *s) {
+  orc_vhash_free(&s->vh);
+  free(s->vox);
+  const double res = o->cfg.voxel_resolution;
+  orc_vhash_init(&s->vh, o->tgt.n);
+  s->vox = (orc_vgvox *)calloc((size_t)o->tgt.n + 1, sizeof(orc_vgvox));
+  for (long i = 0; i < o->tgt.n; i++) {
+    const float *p = o->tgt.xyz + 3 * i;
+    int c[3];
+    for (int a = 0; a < 3; a++) c[a] = (int)floor((double)p[a] / res - 0.5);       /* voxel_coord on Vector4d  :158-160 */
+    orc_vgvox *v = &s->vox[orc_vhash_insert(&s->vh, c[0], c[1], c[2])];
+    v->n++;
+    for (int a = 0; a < 3; a++) v->mean[a] += (double)p[a];
+    for (int a = 0; a < 9; a++) v->cov[a] += s->tgt_cov[9 * i + a];
+  }
+  s->nvox = s->vh.count;
+  for (long j = 0; j < s->nvox; j++) {                                               /* finalize()  :116-121 */
+    for (int a = 0; a < 3; a++) s->vox[j].mean[a] /= s->vox[j].n;
+    for (int a = 0; a < 9; a++) s->vox[j].cov[a] /= s->vox[j].n;
+  }
+  s->vmap_valid = 1;
+}
+
+void orc_gicp_prepare(oracle *o) {
+  orc_gicp_state *s = st(o);
+  if (!s->src_cov || s->src_n != o->src.n) {          /* computeTransformation: lazy covariances  fast_gicp_impl.hpp:102-110 */
+    free(s->src_cov);
+    s->src_cov = (double *)malloc(sizeof(double) * 9 * (size_t)(o->src.n + 1));
+    orc_calc_covariances(o, &o->src, s->src_cov);
+    s->src_n = o->src.n;
+  }
+  if (!s->tgt_cov || s->tgt_n != o->tgt.n) {
+    free(s->tgt_cov);
+    s->tgt_cov = (double *)malloc(sizeof(double) * 9 * (size_t)(o->tgt.n + 1));
+    orc_calc_covariances(o, &o->tgt, s->tgt_cov);
+    s->tgt_n = o->tgt.n;
+    s->tgt_grid_valid = 0;
+    s->vmap_valid = 0;
+  }
+  if (o->cfg.model == ORC_MODEL_GICP && !s->tgt_grid_valid) { grid_build(&s->tgt_grid, &o->tgt, o->cfg.voxel_resolution); s->tgt_grid_valid = 1; }
+  if (o->cfg.model == ORC_MODEL_VGICP && !s->vmap_valid) vgicp_build_voxelmap(o, s);   /* FastVGICP rebuilds it every align; same content */
+}
+
+static const int VG_DIRECT7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+
+static void vg_offsets(int n, int out[27][3]) {
+  if (n == 27) { int t = 0; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) { out[t][0] = i - 1; out[t][1] = j - 1; out[t][2] = k - 1; t++; } }
+  else for (int t = 0; t < n && t < 7; t++) memcpy(out[t], VG_DIRECT7[t], sizeof(int) * 3);
+}
+
+/* M = (cov_B + T cov_A T^T)^-1 on the 3x3 block (the reference inverts the 4x4 with (3,3) = 1)  fast_gicp_impl.hpp:146-150 */
+static void maha3(const double CB[9], const double CA[9], const double T[16], double M[9]) {
+  double RC[9], S[9];
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) RC[a * 3 + b] = T[a * 4 + 0] * CA[0 * 3 + b] + T[a * 4 + 1] * CA[1 * 3 + b] + T[a * 4 + 2] * CA[2 * 3 + b];
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S[a * 3 + b] = CB[a * 3 + b] + (RC[a * 3 + 0] * T[b * 4 + 0] + RC[a * 3 + 1] * T[b * 4 + 1] + RC[a * 3 + 2] * T[b * 4 + 2]);
+  orc_inv3d(S, M);
+}
+
+static double gicp_pass(oracle *o, const double T[16], int update, double *H, double *b) {
+  orc_gicp_state *s = st(o);
+  orc_gicp_prepare(o);
+  const int vg = o->cfg.model == ORC_MODEL_VGICP;
+  const int nO = vg ? (o->cfg.num_neighbors == 27 ? 27 : (o->cfg.num_neighbors == 7 ? 7 : 1)) : 1;
+  int offs[27][3];
+  vg_offsets(nO, offs);
+  const long n = o->src.n;
+  if (s->corr_cap < n * nO) {
+    free(s->corr); free(s->maha);
+    s->corr = (int *)malloc(sizeof(int) * (size_t)(n * nO + 1));
+    s->maha = (double *)malloc(sizeof(double) * 9 * (size_t)(n * nO + 1));
+    s->corr_cap = n * nO;
+  }
+  float Rf[9], tf[3];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rf[i * 3 + j] = (float)T[i * 4 + j]; tf[i] = (float)T[i * 4 + 3]; }
+  const double thr2 = o->cfg.max_corr_dist * o->cfg.max_corr_dist;
+  const double res = o->cfg.voxel_resolution;
+#ifdef _OPENMP
+  const int nth = o->cfg.num_threads > 0 ? o->cfg.num_threads : omp_get_max_threads();
+#else
+  const int nth = 1;
+#endif
+  double *acc = (double *)calloc((size_t)nth * 44, sizeof(double));
+#pragma omp parallel num_threads(nth)
+  {
+#ifdef _OPENMP
+    double *A = acc + (size_t)omp_get_thread_num() * 44;
+#else
+    double *A = acc;
+#endif
+#pragma omp for schedule(dynamic, 64)
+    for (long i = 0; i < n; i++) {
+      const float *p = o->src.xyz + 3 * i;
+      const double pa[3] = {p[0], p[1], p[2]};
+      double q[3];
+      for (int a = 0; a < 3; a++) q[a] = T[a * 4 + 0] * pa[0] + T[a * 4 + 1] * pa[1] + T[a * 4 + 2] * pa[2] + T[a * 4 + 3];
+      for (int k = 0; k < nO; k++) {
+        int j;
+        if (update) {
+          if (vg) {   /* voxel_coord(trans * mean_A) + offset  fast_vgicp_impl.hpp:86-95 */
+            int c[3];
+            for (int a = 0; a < 3; a++) c[a] = (int)floor(q[a] / res - 0.5);
+            j = orc_vhash_find(&s->vh, c[0] + offs[k][0], c[1] + offs[k][1], c[2] + offs[k][2]);
+          } else {    /* pt = trans_f * p (float); kd-tree 1-NN; d2 < corr_dist^2  fast_gicp_impl.hpp:128-136 */
+            float qf[3];
+            for (int a = 0; a < 3; a++) qf[a] = (Rf[a * 3 + 0] * p[0] + Rf[a * 3 + 1] * p[1]) + Rf[a * 3 + 2] * p[2] + tf[a];
+            int id; float d2;
+            const int m = grid_knn(&s->tgt_grid, &o->tgt, qf, 1, thr2, &id, &d2);
+            j = (m == 1 && (double)d2 < thr2) ? id : -1;
+          }
+          s->corr[i * nO + k] = j;
+          if (j >= 0) maha3(vg ? s->vox[j].cov : s->tgt_cov + 9 * (long)j, s->src_cov + 9 * i, T, s->maha + 9 * (i * nO + k));
+        } else {
+          j = s->corr[i * nO + k];
+        }
+        if (j < 0) continue;
+        const double *M = s->maha + 9 * (i * nO + k);
+        double mb[3], w = 1.0;
+        if (vg) { memcpy(mb, s->vox[j].mean, sizeof(mb)); w = sqrt((double)s->vox[j].n); }   /* fast_vgicp_impl.hpp:149 */
+        else for (int a = 0; a < 3; a++) mb[a] = (double)o->tgt.xyz[3 * (long)j + a];
+        double e[3], Me[3];
+        for (int a = 0; a < 3; a++) e[a] = mb[a] - q[a];
+        for (int a = 0; a < 3; a++) Me[a] = M[a * 3 + 0] * e[0] + M[a * 3 + 1] * e[1] + M[a * 3 + 2] * e[2];
+        A[42] += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
+        A[43] += 1.0;
+        if (!H) continue;
+        const double J[3][6] = {{0, -q[2], q[1], -1, 0, 0}, {q[2], 0, -q[0], 0, -1, 0}, {-q[1], q[0], 0, 0, 0, -1}};   /* [skew(Tp), -I] */
+        double JtM[6][3];
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++) JtM[r][c] = J[0][r] * M[0 * 3 + c] + J[1][r] * M[1 * 3 + c] + J[2][r] * M[2 * 3 + c];
+        for (int r = 0; r < 6; r++) {
+          for (int c = 0; c < 6; c++) A[r * 6 + c] += w * (JtM[r][0] * J[0][c] + JtM[r][1] * J[1][c] + JtM[r][2] * J[2][c]);
+          A[36 + r] += w * (JtM[r][0] * e[0] + JtM[r][1] * e[1] + JtM[r][2] * e[2]);
+        }
+      }
+    }
+  }
+  double cost = 0.0, cnt = 0.0;
+  if (H) memset(H, 0, 36 * sizeof(double));
+  if (b) memset(b, 0, 6 * sizeof(double));
+  for (int k = 0; k < nth; k++) {
+    const double *A = acc + (size_t)k * 44;
+    if (H) for (int a = 0; a < 36; a++) H[a] += A[a];
+    if (b) for (int a = 0; a < 6; a++) b[a] += A[36 + a];
+    cost += A[42]; cnt += A[43];
+  }
+  free(acc);
+  o->num_inliers = (int)cnt;
+  return cost;
+}
+
+double orc_gicp_linearize(oracle *o, const double T[16], double *H, double *b) { return gicp_pass(o, T, 1, H, b); }
+double orc_gicp_compute_error(oracle *o, const double T[16]) { return gicp_pass(o, T, 0, NULL, NULL); }
+
+/* unit hooks */
+int orc_test_knn_exact(void *h, const float q[3], int k, int *idx, float *d2) {
+  oracle *o = (oracle *)h;
+  orc_grid g;
+  memset(&g, 0, sizeof(g));
+  grid_build(&g, &o->tgt, o->cfg.voxel_resolution);
+  const int m = grid_knn(&g, &o->tgt, q, k, 1e300, idx, d2);
+  grid_free(&g);
+  return m;
+}
+
+void orc_test_covariances(void *h, int target, double *covs) {
+  oracle *o = (oracle *)h;
+  orc_calc_covariances(o, target ? &o->tgt : &o->src, covs);
+}
