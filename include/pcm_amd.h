@@ -211,6 +211,12 @@ int pcm_map_incremental(pcm_ctx *ctx, const pcm_lio_state *state, float filter_s
 /* current target points in insertion order (x,y,z per point); *n receives the count (query with out = NULL) */
 int pcm_get_target(pcm_ctx *ctx, float *out_xyz, size_t capacity_points, size_t *n);
 
+/* GICP / VGICP: regularised per-point covariances (row-major 3x3 doubles, INPUT order) of the source
+ * (target = 0) or target (target = 1) cloud; computes them if needed.  Query the count with out = NULL.
+ * Replaces FastGICP::getSourceCovariances / getTargetCovariances
+ * (fast_gicp/include/fast_gicp/gicp/fast_gicp.hpp:64-70; computed at impl/fast_gicp_impl.hpp:239-298). */
+int pcm_get_covariances(pcm_ctx *ctx, int target, double *out, size_t capacity_points, size_t *n);
+
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel
  * launches, no host round trip per iteration.  `guesses` = n x 16 floats.

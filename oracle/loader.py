@@ -77,6 +77,8 @@ def lib():
         L.orc_test_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_test_voxel_key.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_test_gauss_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_test_knn_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_test_covariances.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -167,6 +169,18 @@ class Oracle:
         out = np.zeros((n, 3), np.float32)
         if n:
             lib().orc_get_target(self._h, out.ctypes.data)
+        return out
+
+    def knn_exact(self, q, k):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        idx = np.zeros(k, np.int32); d2 = np.zeros(k, np.float32)
+        m = lib().orc_test_knn_exact(self._h, q.ctypes.data, k, idx.ctypes.data, d2.ctypes.data)
+        return idx[:m], d2[:m]
+
+    def covariances(self, target=False):
+        n = self._keep["t" if target else "s"].shape[0]
+        out = np.zeros((n, 3, 3))
+        lib().orc_test_covariances(self._h, 1 if target else 0, out.ctypes.data)
         return out
 
     @property

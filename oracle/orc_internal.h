@@ -42,6 +42,7 @@ typedef struct oracle {
   double *trace;
   int trace_max, trace_n;
   struct orc_gauss_state *gauss;
+  void *gicp;                  /* GICP / VGICP state (orc_gicp.c) */
   struct orc_lru_state *lru;   /* sliding-map state (orc_lru.c) */
   int *nn;                     /* [n_src][5] target indices of the last matching call, -1 = none */
   long nn_cap;
@@ -65,5 +66,14 @@ void orc_gauss_prepare(oracle *o);
 void orc_gauss_invalidate(oracle *o, int target);
 void orc_gauss_swap(oracle *o);
 void orc_gauss_free(oracle *o);
+
+/* orc_gicp.c */
+double orc_gicp_linearize(oracle *o, const double T[16], double *H, double *b);
+double orc_gicp_compute_error(oracle *o, const double T[16]);
+void orc_gicp_prepare(oracle *o);
+void orc_gicp_invalidate(oracle *o, int target);
+void orc_gicp_swap(oracle *o);
+void orc_gicp_free(oracle *o);
+void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs);
 
 #endif

@@ -261,11 +261,7 @@ static double ndt_pass(oracle *o, const double T[16], int update, double *H, dou
 
 double orc_gauss_linearize(oracle *o, const double T[16], double *H, double *b) {
   double Hl[36], bl[6];
-  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D) {   /* GICP / VGICP: not restated yet */
-    if (H) memset(H, 0, 36 * sizeof(double));
-    if (b) memset(b, 0, 6 * sizeof(double));
-    return 0.0;
-  }
+  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D) return orc_gicp_linearize(o, T, H, b);   /* orc_gicp.c */
   const double c = ndt_pass(o, T, 1, Hl, bl);
   if (H) memcpy(H, Hl, sizeof(Hl));
   if (b) memcpy(b, bl, sizeof(bl));
@@ -273,7 +269,7 @@ double orc_gauss_linearize(oracle *o, const double T[16], double *H, double *b) 
 }
 
 double orc_gauss_compute_error(oracle *o, const double T[16]) {
-  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D) return 0.0;
+  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D) return orc_gicp_compute_error(o, T);
   return ndt_pass(o, T, 0, NULL, NULL);
 }
 

@@ -668,6 +668,7 @@ void orc_destroy(void *h) {
   free(o->nn);
   orc_lru_free(o);
   orc_gauss_free(o);
+  orc_gicp_free(o);
   free(o);
 }
 
@@ -677,6 +678,7 @@ int orc_set_target(void *h, const float *xyz, long n, long stride) {
   o->tgt_ivox.valid = 0;
   orc_lru_reset(o);
   orc_gauss_invalidate(o, 1);
+  orc_gicp_invalidate(o, 1);
   return 0;
 }
 
@@ -684,6 +686,7 @@ int orc_set_source(void *h, const float *xyz, long n, long stride) {
   oracle *o = (oracle *)h;
   cloud_set(&o->src, xyz, n, stride);
   orc_gauss_invalidate(o, 0);
+  orc_gicp_invalidate(o, 0);
   return 0;
 }
 
@@ -694,6 +697,7 @@ void orc_swap_source_and_target(void *h) {
   o->tgt_ivox.valid = 0;
   orc_lru_reset(o);
   orc_gauss_swap(o);
+  orc_gicp_swap(o);
 }
 
 double orc_linearize(void *h, const double T[16], double H[36], double b[6]) {
@@ -728,6 +732,7 @@ int orc_trace_count(void *h) { return ((oracle *)h)->trace_n; }
 
 void orc_prepare_model(oracle *o) {
   if (o->cfg.model == ORC_MODEL_P2PLANE) p2plane_prepare(o);
+  else if (o->cfg.model == ORC_MODEL_GICP || o->cfg.model == ORC_MODEL_VGICP) orc_gicp_prepare(o);
   else orc_gauss_prepare(o);
 }
 

@@ -105,6 +105,10 @@ int orc_test_esti_plane(const float *pts_xyz, int n, float threshold, float plan
 int orc_test_knn(void *h, const float q[3], int *idx_out, float *d2_out);
 long orc_test_voxel_key(void *h, const float p[3], int key[3]);
 int orc_test_gauss_voxel(void *h, const float p[3], float mean[3], float cov[9], int *n);
+/* exact k nearest neighbours of q in the target (grid search of orc_gicp.c); returns the count */
+int orc_test_knn_exact(void *h, const float q[3], int k, int *idx, float *d2);
+/* regularised per-point covariances (9 doubles each) of the target (1) or source (0) cloud */
+void orc_test_covariances(void *h, int target, double *covs);
 
 #ifdef __cplusplus
 }

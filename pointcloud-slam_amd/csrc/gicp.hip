@@ -1,0 +1,487 @@
+// gicp.hip -- GICP and VGICP residual models on the brick voxel hash, gfx950.
+//
+// Replaces, for the MI355X path (paths relative to
+// /root/reference/src/pointcloud_match/fast_gicp/include/fast_gicp/gicp):
+//   FastGICP::calculate_covariances ....... impl/fast_gicp_impl.hpp:239-298
+//   FastGICP::update_correspondences ...... impl/fast_gicp_impl.hpp:114-152
+//   FastGICP::linearize / compute_error ... impl/fast_gicp_impl.hpp:154-237
+//   GaussianVoxelMap::create_voxelmap ..... fast_vgicp_voxel.hpp:129-156 (ADDITIVE)
+//   FastVGICP::update_correspondences ..... impl/fast_vgicp_impl.hpp:72-124
+//   FastVGICP::linearize / compute_error .. impl/fast_vgicp_impl.hpp:126-204
+// Shape (not a port): the reference walks a FLANN kd-tree per point.  Here the cloud is already
+// grouped by 8x8x8-voxel brick (voxel_hash.hip), so an exact nearest-neighbour query is a scan of
+// the x-slabs of the <= 8 bricks under the query box -- contiguous point runs, no tree -- with an
+// exactness test (k-th distance inside the box radius) and one guaranteed-sufficient retry at the
+// radius the first pass proved; queries the map cannot answer within 32 voxels fall back to a
+// pruned sweep of the brick table, so the result is the exact Euclidean kNN in every case.
+// The k best candidates of a lane live in LDS as (distance bits << 32 | index) keys.
+// All covariance / Mahalanobis / normal-equation arithmetic is double, as in the reference.
+// Compiled with -ffp-contract=off (see kernels.hip).
+#include "pcm_device.h"
+#include "pcm_host.h"
+#include "dev_linalg.h"
+
+namespace pcm {
+
+namespace {
+
+__device__ inline uint64_t slot_key(const uint4& s) { return ((uint64_t)s.y << 32) | s.x; }
+
+// Visit every map point of the bricks' x-slabs under the box q +- rb.  A point p with
+// |p - q|_inf <= rb lies in a visited slab: the voxel coordinate is monotone in the position.
+template <class F>
+__device__ inline void scan_box(const TargetView& tg, int mode, const float (&q)[3], float rb, F&& visit) {
+  const float lim = (float)(kCoordBias - 64) * tg.res;
+  int lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    lo[a] = voxel_coord(fminf(fmaxf(q[a] - rb, -lim), lim), tg.res, tg.inv_res, mode);
+    hi[a] = voxel_coord(fminf(fmaxf(q[a] + rb, -lim), lim), tg.res, tg.inv_res, mode);
+  }
+  for (int bx = lo[0] >> kBrickShift; bx <= (hi[0] >> kBrickShift); bx++) {
+    const int x0 = (lo[0] > bx * 8 ? lo[0] : bx * 8) & 7, x1 = (hi[0] < bx * 8 + 7 ? hi[0] : bx * 8 + 7) & 7;
+    for (int by = lo[1] >> kBrickShift; by <= (hi[1] >> kBrickShift); by++) {
+      for (int bz = lo[2] >> kBrickShift; bz <= (hi[2] >> kBrickShift); bz++) {
+        const uint64_t key = pack_brick(bx, by, bz);
+        uint32_t h = hash_coord(bx, by, bz) & tg.mask;
+        uint4 s;
+        bool found = false;
+        for (;;) {
+          s = gload4u(&tg.bricks[h]);
+          const uint64_t sk = slot_key(s);
+          if (sk == key) { found = true; break; }
+          if (sk == kEmptyKey) break;
+          h = (h + 1) & tg.mask;
+        }
+        if (!found) continue;
+        const uint32_t vs = s.z + gload_u16(&tg.bpref[(size_t)h * 16 + 2 * x0]);
+        const uint32_t ve = x1 == 7 ? s.z + s.w : s.z + gload_u16(&tg.bpref[(size_t)h * 16 + 2 * (x1 + 1)]);
+        const uint32_t ps = gload_u(&tg.vox_start[vs]), pe = gload_u(&tg.vox_start[ve]);
+        for (uint32_t p = ps; p < pe; p++) {
+          const float4 c = gload4(tg.pts + p);
+          const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
+          visit(p, ex * ex + ey * ey + ez * ez);
+        }
+      }
+    }
+  }
+}
+
+// Sweep of the whole brick table, skipping bricks whose box is provably farther than bound().
+template <class B, class F>
+__device__ inline void scan_all(const TargetView& tg, int mode, const float (&q)[3], B&& bound, F&& visit) {
+  const float shift = mode == COORD_ROUND ? -0.5f : 0.5f;   // voxel c covers [(c + shift) res, (c + shift + 1) res]
+  for (uint32_t h = 0; h <= tg.mask; h++) {
+    const uint4 s = gload4u(&tg.bricks[h]);
+    const uint64_t sk = slot_key(s);
+    if (sk == kEmptyKey) continue;
+    const int b[3] = {(int)(sk >> 36) - kBrickBias, (int)((sk >> 18) & 0x3ffff) - kBrickBias, (int)(sk & 0x3ffff) - kBrickBias};
+    float lb = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float slack = 1e-3f * tg.res + 4e-6f * fabsf(q[a]);
+      const float blo = ((float)(b[a] * 8) + shift) * tg.res - slack, bhi = ((float)(b[a] * 8 + 8) + shift) * tg.res + slack;
+      const float d = fmaxf(fmaxf(blo - q[a], q[a] - bhi), 0.f);
+      lb += d * d;
+    }
+    if (lb * 0.999f > bound()) continue;
+    const uint4 s2 = gload4u(reinterpret_cast<const uint4*>(&tg.bricks[h]) + 1);   // pt_start, npts
+    for (uint32_t p = s2.x; p < s2.x + s2.y; p++) {
+      const float4 c = gload4(tg.pts + p);
+      const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
+      visit(p, ex * ex + ey * ey + ez * ez);
+    }
+  }
+}
+
+__device__ inline bool finite3(const float (&q)[3]) { return isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]); }
+
+// exact nearest map point of q: index or -1 when (double)d2 >= max_sq   (nearestKSearch(pt, 1) + the threshold of fast_gicp_impl.hpp:136)
+__device__ inline int nearest1(const TargetView& tg, int mode, const float (&q)[3], double max_sq) {
+  if (!finite3(q)) return -1;
+  uint64_t best = ~0ull;
+  auto visit = [&](uint32_t p, float d2) {
+    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | p;
+    if (d2 == d2 && key < best) best = key;
+  };
+  float r = tg.res;
+  bool exact = false;
+  for (;;) {
+    best = ~0ull;
+    scan_box(tg, mode, q, r * 1.0001f, visit);
+    const float d2 = __uint_as_float((uint32_t)(best >> 32));
+    if (best != ~0ull && d2 < r * r) { exact = true; break; }
+    if ((double)r * (double)r >= max_sq) { exact = true; break; }   // nothing closer than the threshold exists
+    const float rn = best != ~0ull ? sqrtf(d2) * 1.001f : 2.f * r;
+    if (rn > 32.f * tg.res) break;
+    r = rn;
+  }
+  if (!exact) {
+    best = ~0ull;
+    scan_all(tg, mode, q, [&]() { return best == ~0ull ? 3.0e38f : __uint_as_float((uint32_t)(best >> 32)); }, visit);
+  }
+  if (best == ~0ull) return -1;
+  const float d2 = __uint_as_float((uint32_t)(best >> 32));
+  return (double)d2 < max_sq ? (int)(uint32_t)best : -1;
+}
+
+__device__ inline void regularize_cov(int method, const double (&cov)[9], double (&out)[9]) {
+  if (method == PCM_REG_NONE) {
+#pragma unroll
+    for (int a = 0; a < 9; a++) out[a] = cov[a];
+    return;
+  }
+  if (method == PCM_REG_FROBENIUS) {   // fast_gicp_impl.hpp:266-271
+    double C[9], Ci[9], N[9];
+#pragma unroll
+    for (int a = 0; a < 9; a++) C[a] = cov[a];
+    C[0] += 1e-3; C[4] += 1e-3; C[8] += 1e-3;
+    inv3<double>(C, Ci);
+    double nrm = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; a++) nrm += Ci[a] * Ci[a];
+    nrm = sqrt(nrm);
+#pragma unroll
+    for (int a = 0; a < 9; a++) N[a] = Ci[a] / nrm;
+    inv3<double>(N, out);
+    return;
+  }
+  double w[3], V[9], val[3];
+  eig3_sym_jacobi(cov, w, V);   // ascending; the SVD's singular values are these in descending order
+  if (method == PCM_REG_PLANE) { val[0] = 1e-3; val[1] = 1.0; val[2] = 1.0; }
+  else if (method == PCM_REG_MIN_EIG) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) val[k] = w[k] > 1e-3 ? w[k] : 1e-3;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const double v = w[k] / w[2]; val[k] = v > 1e-3 ? v : 1e-3; }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) s += V[a * 3 + k] * val[k] * V[b * 3 + k];
+      out[a * 3 + b] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_covariances: one lane per map point (brick-major order: the lanes of a workgroup query
+// neighbouring boxes, so the point runs they scan are shared through L2).
+// dynamic LDS: k x 256 keys
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, int k, int reg, double* __restrict__ out) {
+  extern __shared__ uint64_t s_top[];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i = blockIdx.x * 256 + tid;
+  if (i >= tg.num_points) return;
+  const float4 pq = gload4(tg.pts + i);
+  const float q[3] = {pq.x, pq.y, pq.z};
+  int n = 0;
+  uint64_t worst = ~0ull;
+  auto visit = [&](uint32_t p, float d2) {
+    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | p;
+    if (!(d2 == d2) || (n == k && key >= worst)) return;
+    int pos = n < k ? n : k - 1;
+    while (pos > 0) {
+      const uint64_t prev = s_top[(pos - 1) * 256 + tid];
+      if (prev <= key) break;
+      s_top[pos * 256 + tid] = prev;
+      pos--;
+    }
+    s_top[pos * 256 + tid] = key;
+    if (n < k) n++;
+    if (n == k) worst = s_top[(k - 1) * 256 + tid];
+  };
+  float r = 2.f * tg.res;
+  bool exact = false;
+  for (;;) {
+    n = 0; worst = ~0ull;
+    scan_box(tg, mode, q, r * 1.0001f, visit);
+    float rn = 2.f * r;
+    if (n == k) {
+      const float d2k = __uint_as_float((uint32_t)(worst >> 32));
+      if (d2k < r * r) { exact = true; break; }
+      rn = sqrtf(d2k) * 1.001f;   // the k points already seen lie inside this radius: the next pass is exact
+    }
+    if (rn > 32.f * tg.res) break;
+    r = rn;
+  }
+  if (!exact) {
+    n = 0; worst = ~0ull;
+    scan_all(tg, mode, q, [&]() { return n == k ? __uint_as_float((uint32_t)(worst >> 32)) : 3.0e38f; }, visit);
+  }
+  // neighbours (k columns; the mean and the covariance divide by k)  fast_gicp_impl.hpp:254-260
+  double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int j = 0; j < n; j++) {
+    const float4 c = gload4(tg.pts + (uint32_t)s_top[j * 256 + tid]);
+    mean[0] += (double)c.x; mean[1] += (double)c.y; mean[2] += (double)c.z;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) mean[a] /= (double)k;
+  for (int j = 0; j < n; j++) {
+    const float4 c = gload4(tg.pts + (uint32_t)s_top[j * 256 + tid]);
+    const double d[3] = {(double)c.x - mean[0], (double)c.y - mean[1], (double)c.z - mean[2]};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) cov[a * 3 + b] += d[a] * d[b];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 9; a++) cov[a] /= (double)k;
+  double R[9];
+  regularize_cov(reg, cov, R);
+  double* o = out + (size_t)i * 6;
+  gstore_d(o + 0, R[0]); gstore_d(o + 1, R[1]); gstore_d(o + 2, R[2]);
+  gstore_d(o + 3, R[4]); gstore_d(o + 4, R[5]); gstore_d(o + 5, R[8]);
+}
+
+// voxel distributions of the VGICP map: a voxel's points are one run in input order
+__global__ void __launch_bounds__(128) k_vgicp_voxels(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, const double* __restrict__ covs,
+                                                      uint32_t nvox, VgVoxel* __restrict__ out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t p0 = vox_start[v], p1 = vox_start[v + 1];
+  VgVoxel g;
+#pragma unroll
+  for (int a = 0; a < 3; a++) g.mean[a] = 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) g.cov[a] = 0.0;
+  for (uint32_t p = p0; p < p1; p++) {   // append()  fast_vgicp_voxel.hpp:111-115
+    const float4 c = pts[p];
+    g.mean[0] += (double)c.x; g.mean[1] += (double)c.y; g.mean[2] += (double)c.z;
+#pragma unroll
+    for (int a = 0; a < 6; a++) g.cov[a] += covs[(size_t)p * 6 + a];
+  }
+  g.n = (int32_t)(p1 - p0);
+  g.pad = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) g.mean[a] /= g.n;   // finalize()  :117-120
+#pragma unroll
+  for (int a = 0; a < 6; a++) g.cov[a] /= g.n;
+  out[v] = g;
+}
+
+__constant__ int8_t c_vg_direct7[7][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {-1, 0, 0, 0}, {0, 1, 0, 0}, {0, -1, 0, 0}, {0, 0, 1, 0}, {0, 0, -1, 0}};
+
+// voxel index of cell (vx,vy,vz) or -1
+__device__ inline int vg_lookup(const TargetView& tg, int vx, int vy, int vz) {
+  const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
+  const uint64_t key = pack_brick(bx, by, bz);
+  uint32_t h = hash_coord(bx, by, bz) & tg.mask;
+  uint4 s;
+  for (;;) {
+    s = gload4u(&tg.bricks[h]);
+    const uint64_t sk = slot_key(s);
+    if (sk == key) break;
+    if (sk == kEmptyKey) return -1;
+    h = (h + 1) & tg.mask;
+  }
+  const uint32_t li = local_index(vx, vy, vz), w = li >> 5, bit = li & 31;
+  const uint32_t m = gload_u(&tg.bmask[(size_t)h * 16 + w]);
+  if (!((m >> bit) & 1u)) return -1;
+  return (int)(s.z + gload_u16(&tg.bpref[(size_t)h * 16 + w]) + (uint32_t)__popc(m & ((1u << bit) - 1u)));
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ inline void load6(const double* p, double (&C)[9]) {
+  const double a = gload_d(p), b = gload_d(p + 1), c = gload_d(p + 2), d = gload_d(p + 3), e = gload_d(p + 4), f = gload_d(p + 5);
+  C[0] = a; C[1] = b; C[2] = c; C[3] = b; C[4] = d; C[5] = e; C[6] = c; C[7] = e; C[8] = f;
+}
+
+// ---------------------------------------------------------------------------
+// k_gicp: TRIAL = false -> correspondences + Mahalanobis matrices at x0, H, b, cost (linearize)
+//         TRIAL = true  -> cost of the remembered correspondences / matrices at xi (compute_error)
+// grid = (blocks, npairs), block = 256
+// ---------------------------------------------------------------------------
+template <bool VG, bool TRIAL>
+__global__ void __launch_bounds__(256) k_gicp(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
+  const int pair = blockIdx.y;
+  const int mode = states[pair].mode;
+  if (mode != (TRIAL ? MODE_TRIAL : MODE_LINEARIZE)) return;
+  const PairDesc d = descs[pair];
+  const uint32_t per = (uint32_t)(TRIAL ? kp.points_per_block : kp.lin_points_per_block);
+  const uint32_t begin = blockIdx.x * per;
+  if (begin >= d.src.num_points) return;
+  uint32_t end = begin + per;
+  end = end < d.src.num_points ? end : d.src.num_points;
+  const TargetView tg = d.tgt;
+  const int nO = VG ? kp.num_neighbors : 1;
+  double T[12];
+  float Rf[9], tf[3];
+  {
+    const double* Ts = TRIAL ? states[pair].xi : states[pair].x0;
+#pragma unroll
+    for (int a = 0; a < 12; a++) T[a] = Ts[a];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) Rf[i * 3 + j] = (float)T[i * 4 + j];   // trans.cast<float>()
+      tf[i] = (float)T[i * 4 + 3];
+    }
+  }
+  double acc[kNumSums];
+#pragma unroll
+  for (int j = 0; j < kNumSums; j++) acc[j] = 0.0;
+
+  for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+    const float4 p = gload4(d.src.pts + i);
+    const double pa[3] = {(double)p.x, (double)p.y, (double)p.z};
+    double q[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) q[a] = T[a * 4 + 0] * pa[0] + T[a * 4 + 1] * pa[1] + T[a * 4 + 2] * pa[2] + T[a * 4 + 3];
+    int c[3] = {0, 0, 0};
+    bool inrange = true;
+    if (VG && !TRIAL) {   // voxel_coord(trans * mean_A)  fast_vgicp_impl.hpp:88
+      const double res = (double)tg.res, lim = (double)(kCoordBias - 32);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double f = floor(q[a] / res - 0.5);
+        inrange = inrange && fabs(f) < lim;
+        c[a] = inrange ? (int)f : 0;
+      }
+    }
+    double CA[9];
+    if (!TRIAL) load6(d.src_cov + (size_t)i * 6, CA);
+    for (int k = 0; k < nO; k++) {
+      int j;
+      double* mp = d.maha + ((size_t)i * nO + k) * 6;
+      double M[9];
+      if (TRIAL) {
+        j = *(const PCM_GLOBAL int32_t*)(d.corr + (size_t)i * nO + k);
+        if (j < 0) continue;
+        load6(mp, M);
+      } else {
+        if (VG) {
+          int ox, oy, oz;
+          if (nO == 27) { ox = k / 9 - 1; oy = (k / 3) % 3 - 1; oz = k % 3 - 1; }
+          else { ox = c_vg_direct7[k][0]; oy = c_vg_direct7[k][1]; oz = c_vg_direct7[k][2]; }
+          j = inrange ? vg_lookup(tg, c[0] + ox, c[1] + oy, c[2] + oz) : -1;
+        } else {
+          float qf[3];   // pt = trans_f * p   fast_gicp_impl.hpp:128-131
+#pragma unroll
+          for (int a = 0; a < 3; a++) qf[a] = (Rf[a * 3 + 0] * p.x + Rf[a * 3 + 1] * p.y) + Rf[a * 3 + 2] * p.z + tf[a];
+          j = nearest1(tg, kp.coord_mode, qf, kp.max_corr_sq);
+        }
+        *(PCM_GLOBAL int32_t*)(d.corr + (size_t)i * nO + k) = j;
+        if (j < 0) continue;
+        // RCR = cov_B + T cov_A T^T ; M = RCR^-1   fast_gicp_impl.hpp:146-150
+        double CB[9], RC[9], S[9];
+        load6(VG ? d.vvox[j].cov : d.tgt_cov + (size_t)j * 6, CB);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+          for (int b = 0; b < 3; b++) RC[a * 3 + b] = T[a * 4 + 0] * CA[0 * 3 + b] + T[a * 4 + 1] * CA[1 * 3 + b] + T[a * 4 + 2] * CA[2 * 3 + b];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+          for (int b = 0; b < 3; b++) S[a * 3 + b] = CB[a * 3 + b] + (RC[a * 3 + 0] * T[b * 4 + 0] + RC[a * 3 + 1] * T[b * 4 + 1] + RC[a * 3 + 2] * T[b * 4 + 2]);
+        }
+        inv3<double>(S, M);
+        M[3] = M[1]; M[6] = M[2]; M[7] = M[5];   // stored symmetric (upper triangle)
+        gstore_d(mp + 0, M[0]); gstore_d(mp + 1, M[1]); gstore_d(mp + 2, M[2]);
+        gstore_d(mp + 3, M[4]); gstore_d(mp + 4, M[5]); gstore_d(mp + 5, M[8]);
+      }
+      double mb[3], w = 1.0;
+      if (VG) {
+        const VgVoxel* v = d.vvox + j;
+        mb[0] = gload_d(&v->mean[0]); mb[1] = gload_d(&v->mean[1]); mb[2] = gload_d(&v->mean[2]);
+        w = sqrt((double)*(const PCM_GLOBAL int32_t*)&v->n);   // fast_vgicp_impl.hpp:149
+      } else {
+        const float4 m4 = gload4(tg.pts + j);
+        mb[0] = (double)m4.x; mb[1] = (double)m4.y; mb[2] = (double)m4.z;
+      }
+      double e[3], Me[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) e[a] = mb[a] - q[a];
+#pragma unroll
+      for (int a = 0; a < 3; a++) Me[a] = M[a * 3 + 0] * e[0] + M[a * 3 + 1] * e[1] + M[a * 3 + 2] * e[2];
+      acc[27] += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
+      acc[28] += 1.0;
+      if (TRIAL) continue;
+      // J = [skew(T p), -I]; H += w J^T M J ; b += w J^T M e
+      const double J[3][6] = {{0.0, -q[2], q[1], -1.0, 0.0, 0.0}, {q[2], 0.0, -q[0], 0.0, -1.0, 0.0}, {-q[1], q[0], 0.0, 0.0, 0.0, -1.0}};
+      double JtM[6][3];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) JtM[r][cc] = J[0][r] * M[0 * 3 + cc] + J[1][r] * M[1 * 3 + cc] + J[2][r] * M[2 * 3 + cc];
+      }
+      int tt = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+#pragma unroll
+        for (int cc = r; cc < 6; cc++) { acc[tt] += w * (JtM[r][0] * J[0][cc] + JtM[r][1] * J[1][cc] + JtM[r][2] * J[2][cc]); tt++; }
+      }
+#pragma unroll
+      for (int r = 0; r < 6; r++) acc[21 + r] += w * (JtM[r][0] * e[0] + JtM[r][1] * e[1] + JtM[r][2] * e[2]);
+    }
+  }
+
+  __shared__ double s_part[4][kPartialStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < kNumSums; j++) {
+    const double v = wave_sum(acc[j]);
+    if (lane == 0) s_part[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums) {
+    const double v = ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x];
+    gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+  }
+}
+
+TargetView view_of(const TargetMap& m) {
+  TargetView v{};
+  v.pts = m.pts; v.vox_start = m.vox_start; v.bricks = m.bricks; v.bmask = m.bmask; v.bpref = m.bpref; v.gvox = m.gvox;
+  v.mask = m.cap - 1; v.num_points = m.num_points; v.inv_res = m.inv_res; v.res = m.res;
+  return v;
+}
+
+}  // namespace
+
+// regularised kNN covariance of every point of `map` (map order), 6 doubles each
+int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err) {
+  if (k < 1 || k > 64) { *err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
+  const size_t lds = sizeof(uint64_t) * 256 * (size_t)k;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_covariances), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      *err = "cannot reserve LDS for the kNN keys"; return PCM_ERR_HIP;
+    }
+  }
+  k_covariances<<<(map.num_points + 255) / 256, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { *err = std::string("k_covariances: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return PCM_OK;
+}
+
+int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgVoxel* d_out, std::string* err) {
+  k_vgicp_voxels<<<(map.num_voxels + 127) / 128, 128, 0, stream>>>(map.pts, map.vox_start, d_cov, map.num_voxels, d_out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { *err = std::string("k_vgicp_voxels: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return PCM_OK;
+}
+
+void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial) {
+  dim3 grid((unsigned)(trial ? kp.blocks_per_pair : kp.tiles_per_pair), (unsigned)npairs);
+  if (vgicp) {
+    if (trial) k_gicp<true, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+    else k_gicp<true, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+  } else {
+    if (trial) k_gicp<false, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+    else k_gicp<false, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+  }
+}
+
+}  // namespace pcm

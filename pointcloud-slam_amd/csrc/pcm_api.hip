@@ -107,15 +107,26 @@ void free_ws(pcm_ctx* c) {
   c->ws = nullptr;
 }
 
-int coord_mode_for(int model) { return model == PCM_MODEL_P2PLANE ? COORD_ROUND : COORD_FLOOR_HALF; }
+int coord_mode_for(int model) {
+  if (model == PCM_MODEL_P2PLANE || model == PCM_MODEL_GICP) return COORD_ROUND;   // GICP: the grid is only the kNN index, any convention serves
+  return model == PCM_MODEL_VGICP ? COORD_FLOOR_HALF_D : COORD_FLOOR_HALF;
+}
 
 size_t num_elements(const pcm_ctx* c) { return c->cfg.model == PCM_MODEL_NDT_D2D ? (size_t)c->srcmap.num_voxels : c->src.n; }
 
 bool is_ndt(int model) { return model == PCM_MODEL_NDT_P2D || model == PCM_MODEL_NDT_D2D; }
+bool is_gicp(int model) { return model == PCM_MODEL_GICP || model == PCM_MODEL_VGICP; }
 
 int validate_config(pcm_ctx* c, const pcm_config& g) {
-  if (g.model != PCM_MODEL_P2PLANE && !is_ndt(g.model)) { c->err = "model not built in this library revision (P2PLANE, NDT_P2D, NDT_D2D are)"; return PCM_ERR_UNSUPPORTED; }
-  if (is_ndt(g.model) && g.num_neighbors == 19) { c->err = "NDT neighbourhoods are DIRECT1 / DIRECT7 / DIRECT27 (num_neighbors 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (g.model != PCM_MODEL_P2PLANE && !is_ndt(g.model) && !is_gicp(g.model)) { c->err = "unknown registration model"; return PCM_ERR_UNSUPPORTED; }
+  if ((is_ndt(g.model) || g.model == PCM_MODEL_VGICP) && g.num_neighbors == 19) {
+    c->err = "NDT / VGICP neighbourhoods are DIRECT1 / DIRECT7 / DIRECT27 (num_neighbors 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT;
+  }
+  if (is_gicp(g.model)) {
+    if (g.k_correspondences < 1 || g.k_correspondences > 64) { c->err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (g.regularization < PCM_REG_NONE || g.regularization > PCM_REG_FROBENIUS) { c->err = "bad regularization method"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (!(g.max_corr_dist > 0.f)) { c->err = "max_corr_dist must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
+  }
   if (g.optimizer != PCM_OPT_GAUSS_NEWTON && g.optimizer != PCM_OPT_LEVENBERG_MARQUARDT) { c->err = "bad optimizer"; return PCM_ERR_INVALID_ARGUMENT; }
   if (!(g.voxel_resolution > 0.f)) { c->err = "voxel_resolution must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
   if (g.num_neighbors != 1 && g.num_neighbors != 7 && g.num_neighbors != 19 && g.num_neighbors != 27) {
@@ -162,13 +173,69 @@ int prepare(pcm_ctx* c) {
   HIPCK(c, hipSetDevice(c->device));
   const int mode = coord_mode_for(c->cfg.model);
   const bool gauss = is_ndt(c->cfg.model);
-  if (!c->map.valid || c->map.res != c->cfg.voxel_resolution || c->map.coord_mode != mode || (gauss && !c->map.gvox)) {
+  const bool gicp = is_gicp(c->cfg.model);
+  if (!c->map.valid || c->map.res != c->cfg.voxel_resolution || c->map.coord_mode != mode || (gauss && !c->map.gvox) || (gicp && !c->map.order)) {
     uint32_t n_log = (uint32_t)c->tgt.n;
-    int rc = build_target_map(c->stream, c->tgt.d_pts, &n_log, c->cfg.voxel_resolution, mode, gauss, (uint32_t)std::max(0, c->cfg.map_capacity), &c->map, &c->err);
+    // the sliding-map capacity belongs to the iVox of the P2PLANE / LIO path; fast_gicp keeps every target point
+    const uint32_t capacity = c->cfg.model == PCM_MODEL_P2PLANE ? (uint32_t)std::max(0, c->cfg.map_capacity) : 0u;
+    int rc = build_target_map(c->stream, c->tgt.d_pts, &n_log, c->cfg.voxel_resolution, mode, gauss, capacity, &c->map, &c->err, gicp);
     c->tgt.n = n_log;   // LRU eviction compacts the point log
     if (rc != PCM_OK) return rc;
     c->stats.target_voxels = c->map.num_voxels;
     c->stats.target_slots = c->map.cap;
+    c->tgt_cov_valid = false;
+  }
+  if (gicp) {
+    // FastGICP::computeTransformation: covariances of both clouds, lazily   fast_gicp_impl.hpp:102-110
+    if (c->cov_k != c->cfg.k_correspondences || c->cov_reg != c->cfg.regularization) {
+      c->src_cov_valid = false; c->tgt_cov_valid = false;
+      c->cov_k = c->cfg.k_correspondences; c->cov_reg = c->cfg.regularization;
+    }
+    if (!c->srcmap.valid || c->srcmap.res != c->cfg.voxel_resolution || c->srcmap.coord_mode != mode) {
+      uint32_t n_src = (uint32_t)c->src.n;
+      int rc = build_target_map(c->stream, c->src.d_pts, &n_src, c->cfg.voxel_resolution, mode, false, 0u, &c->srcmap, &c->err, true);
+      if (rc != PCM_OK) return rc;
+      c->src_cov_valid = false;
+    }
+    if (!c->tgt_cov_valid) {
+      if (c->tgt_cov_cap < c->map.num_points) {
+        if (c->tgt_cov) hipFree(c->tgt_cov);
+        c->tgt_cov = nullptr; c->tgt_cov_cap = 0;
+        HIPCK(c, hipMalloc(&c->tgt_cov, sizeof(double) * 6 * (size_t)c->map.num_points));
+        c->tgt_cov_cap = c->map.num_points;
+      }
+      int rc = compute_covariances(c->stream, c->map, c->cfg.k_correspondences, c->cfg.regularization, c->tgt_cov, &c->err);
+      if (rc != PCM_OK) return rc;
+      if (c->cfg.model == PCM_MODEL_VGICP) {
+        if (c->vvox_cap < c->map.num_voxels) {
+          if (c->vvox) hipFree(c->vvox);
+          c->vvox = nullptr; c->vvox_cap = 0;
+          HIPCK(c, hipMalloc(&c->vvox, sizeof(VgVoxel) * (size_t)c->map.num_voxels));
+          c->vvox_cap = c->map.num_voxels;
+        }
+        rc = build_vgicp_voxels(c->stream, c->map, c->tgt_cov, c->vvox, &c->err);
+        if (rc != PCM_OK) return rc;
+      }
+      c->tgt_cov_valid = true;
+    }
+    if (!c->src_cov_valid) {
+      if (c->src_cov_cap < c->srcmap.num_points) {
+        if (c->src_cov) hipFree(c->src_cov);
+        c->src_cov = nullptr; c->src_cov_cap = 0;
+        HIPCK(c, hipMalloc(&c->src_cov, sizeof(double) * 6 * (size_t)c->srcmap.num_points));
+        c->src_cov_cap = c->srcmap.num_points;
+      }
+      int rc = compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization, c->src_cov, &c->err);
+      if (rc != PCM_OK) return rc;
+      c->src_cov_valid = true;
+    }
+    const size_t ncorr = c->src.n * (size_t)(c->cfg.model == PCM_MODEL_VGICP ? c->cfg.num_neighbors : 1);
+    if (c->maha_cap < ncorr) {
+      if (c->maha) hipFree(c->maha);
+      c->maha = nullptr; c->maha_cap = 0;
+      HIPCK(c, hipMalloc(&c->maha, sizeof(double) * 6 * ncorr));
+      c->maha_cap = ncorr;
+    }
   }
   if (c->cfg.model == PCM_MODEL_NDT_D2D && (!c->srcmap.valid || c->srcmap.res != c->cfg.voxel_resolution)) {
     // D2D: the source elements are the source-voxel distributions (ndt_cuda.cu:120-129,156-158)
@@ -176,8 +243,8 @@ int prepare(pcm_ctx* c) {
     int rc = build_target_map(c->stream, c->src.d_pts, &n_src, c->cfg.voxel_resolution, mode, true, 0u, &c->srcmap, &c->err);
     if (rc != PCM_OK) return rc;
   }
-  if (gauss) {
-    const size_t need = num_elements(c) * (size_t)c->cfg.num_neighbors;
+  if (gauss || gicp) {
+    const size_t need = num_elements(c) * (size_t)(c->cfg.model == PCM_MODEL_GICP ? 1 : c->cfg.num_neighbors);
     if (c->corr_cap < need) {
       if (c->corr) hipFree(c->corr);
       c->corr = nullptr; c->corr_cap = 0;
@@ -242,6 +309,11 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->tgt.res = c->map.res;
   d->tgt.gvox = c->map.gvox;
   d->src.pts = (c->cfg.sort_source && c->src_sorted) ? c->src_order : c->src.d_pts;
+  if (is_gicp(c->cfg.model)) d->src.pts = c->srcmap.pts;   // brick-major copy of the scan: its covariances are in that order
+  d->src_cov = c->src_cov;
+  d->tgt_cov = c->tgt_cov;
+  d->vvox = c->vvox;
+  d->maha = c->maha;
   d->src.gvox = c->srcmap.gvox;
   d->src.num_points = (uint32_t)num_elements(c);
   d->corr = c->corr;
@@ -269,6 +341,8 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
   kp.do_step = 1;
   kp.lin_points_per_block = is_ndt(g.model) ? geom.points_per_block : 256;
+  kp.coord_mode = coord_mode_for(g.model);
+  kp.max_corr_sq = (double)g.max_corr_dist * (double)g.max_corr_dist;
   return kp;
 }
 
@@ -287,7 +361,7 @@ bool same_solver_config(const pcm_config& a, const pcm_config& b) {
   return a.model == b.model && a.optimizer == b.optimizer && a.max_iterations == b.max_iterations && a.lm_max_iterations == b.lm_max_iterations &&
          a.rotation_eps == b.rotation_eps && a.translation_eps == b.translation_eps && a.lm_init_lambda_factor == b.lm_init_lambda_factor &&
          a.num_neighbors == b.num_neighbors && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold && a.flags == b.flags &&
-         (a.model == PCM_MODEL_P2PLANE || a.voxel_resolution == b.voxel_resolution);
+         (a.model == PCM_MODEL_P2PLANE || a.voxel_resolution == b.voxel_resolution) && (!is_gicp(a.model) || a.max_corr_dist == b.max_corr_dist);
 }
 
 int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_result* host_out, void* device_out) {
@@ -309,6 +383,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   }
   const pcm_config& g = c0->cfg;
   const bool ndt = is_ndt(g.model);
+  const bool gicp = is_gicp(g.model);
   const Geom geom = pick_geom(max_n, n, ndt);
   const LsqParams lp = lsq_params(g);
   const KernelParams kp = kernel_params(g, geom);
@@ -326,7 +401,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     uint32_t total = 0, jmax = 0;
     for (int i = 0; i < n; i++) {
       pcm_ctx* c = ctxs[i];
-      if (!c->cfg.sort_source || c->src_sorted || c->cfg.model == PCM_MODEL_NDT_D2D) continue;
+      if (!c->cfg.sort_source || c->src_sorted || c->cfg.model == PCM_MODEL_NDT_D2D || gicp) continue;
       SortJob j{c->src.d_pts, c->src_order, (uint32_t)c->src.n, total, (uint32_t)i, 0};
       jobs.push_back(j);
       total += j.n;
@@ -336,7 +411,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       HIPCK(c0, hipMemcpyAsync(w->d_jobs, jobs.data(), sizeof(SortJob) * jobs.size(), hipMemcpyHostToDevice, st));
       rc = sort_sources_batched(st, w->d_jobs, (int)jobs.size(), jmax, total, w->d_guesses, g.voxel_resolution, &w->sort, &c0->err);
       if (rc != PCM_OK) return rc;
-      for (int i = 0; i < n; i++) if (ctxs[i]->cfg.sort_source) ctxs[i]->src_sorted = true;
+      for (const SortJob& j : jobs) ctxs[j.guess_index]->src_sorted = true;
     }
   }
   std::vector<PairDesc> descs(n);
@@ -361,11 +436,13 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
     if (ndt) launch_ndt(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_NDT_D2D, false);
+    else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_VGICP, false);
     else launch_linearize(st, w->d_descs, w->d_states, kp, n, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
     launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums);
     if (is_lm) {
       if (ndt) launch_ndt(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_NDT_D2D, true);
+      else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_VGICP, true);
       else launch_trial(st, w->d_descs, w->d_states, kp, n);
       launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, true, true, w->d_flags + (size_t)r * n, w->d_sums);
     }
@@ -451,6 +528,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   KernelParams kp1 = kp;
   kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
   if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_NDT_D2D, !linearize);
+  else if (is_gicp(c->cfg.model)) launch_gicp(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_VGICP, !linearize);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
   launch_finish_round(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, !linearize, false, w->d_flags, w->d_sums);
@@ -521,6 +599,10 @@ void pcm_destroy(pcm_ctx* c) {
     c->map.release();
     c->srcmap.release();
     if (c->corr) hipFree(c->corr);
+    if (c->src_cov) hipFree(c->src_cov);
+    if (c->tgt_cov) hipFree(c->tgt_cov);
+    if (c->vvox) hipFree(c->vvox);
+    if (c->maha) hipFree(c->maha);
     if (c->planes) hipFree(c->planes);
     if (c->counter) hipFree(c->counter);
     if (c->nn) hipFree(c->nn);
@@ -600,6 +682,32 @@ int pcm_clear_source(pcm_ctx* c) {
 int pcm_clear_target(pcm_ctx* c) {
   CHECK_CTX(c);
   c->tgt.n = 0; c->tgt.tag = 0; c->map.valid = false;
+  return PCM_OK;
+}
+
+// getSourceCovariances / getTargetCovariances  fast_gicp.hpp:64-70  (input order, row-major 3x3 blocks)
+int pcm_get_covariances(pcm_ctx* c, int target, double* out, size_t capacity_points, size_t* n) {
+  CHECK_CTX(c);
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  if (!is_gicp(c->cfg.model)) { c->err = "covariances exist for the GICP / VGICP models only"; return PCM_ERR_UNSUPPORTED; }
+  rc = prepare(c);
+  if (rc != PCM_OK) return rc;
+  const TargetMap& m = target ? c->map : c->srcmap;
+  const double* d_cov = target ? c->tgt_cov : c->src_cov;
+  if (n) *n = m.num_points;
+  if (!out) return PCM_OK;
+  if (capacity_points < m.num_points) { c->err = "output buffer too small"; return PCM_ERR_INVALID_ARGUMENT; }
+  std::vector<double> h6((size_t)m.num_points * 6);
+  std::vector<uint32_t> ord(m.num_points);
+  HIPCK(c, hipMemcpyAsync(h6.data(), d_cov, sizeof(double) * h6.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipMemcpyAsync(ord.data(), m.order, sizeof(uint32_t) * ord.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < ord.size(); i++) {
+    const double* s = &h6[i * 6];
+    double* o = out + (size_t)ord[i] * 9;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[1]; o[4] = s[3]; o[5] = s[4]; o[6] = s[2]; o[7] = s[4]; o[8] = s[5];
+  }
   return PCM_OK;
 }
 

@@ -74,8 +74,24 @@ static_assert(sizeof(GaussVoxel) == 48, "GaussVoxel must be 48 bytes");
 // voxel-coordinate conventions of the reference
 enum CoordMode : int32_t {
   COORD_ROUND = 0,       // iVox Pos2Grid: round(p * inv_res)          jueying_lio/include/ivox3d/ivox3d.h:283-286
-  COORD_FLOOR_HALF = 1   // fast_gicp: floor(p / res - 0.5)            include/fast_gicp/cuda/vector3_hash.cuh:35-38
+  COORD_FLOOR_HALF = 1,  // fast_gicp CUDA: floor(p / res - 0.5), float  include/fast_gicp/cuda/vector3_hash.cuh:35-38
+  COORD_FLOOR_HALF_D = 2 // fast_gicp CPU VGICP: the same in double     include/fast_gicp/gicp/fast_vgicp_voxel.hpp:158-160
 };
+
+__host__ __device__ inline int voxel_coord(float v, float res, float inv_res, int mode) {
+  if (mode == COORD_ROUND) return (int)roundf(v * inv_res);
+  if (mode == COORD_FLOOR_HALF) return (int)floorf(v / res - 0.5f);
+  return (int)floor((double)v / (double)res - 0.5);
+}
+
+// voxel payload of the CPU-semantics VGICP model (AdditiveGaussianVoxel, fast_vgicp_voxel.hpp:104-122): doubles
+struct VgVoxel {
+  double mean[3];
+  double cov[6];     // xx xy xz yy yz zz
+  int32_t n;
+  int32_t pad;
+};
+static_assert(sizeof(VgVoxel) == 80, "VgVoxel must be 80 bytes");
 
 // Explicit global-address-space accessors.  Pointers that reach a kernel through a
 // descriptor struct are generic to the compiler; a generic (flat) load counts on
@@ -143,7 +159,11 @@ struct PairDesc {
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
   LioPose lio;          // LIO measurement model only
   uint32_t* nn;         // LIO: [N][5] neighbour indices into tgt.pts (~0u: none) from the last matching call
-  int32_t* corr;        // NDT: [elements][offsets] matched target voxel (or -1) of the last linearize
+  int32_t* corr;        // NDT / VGICP: [elements][offsets] matched target voxel (or -1) of the last linearize; GICP: [N] matched target point
+  const double* src_cov;   // GICP / VGICP: [N][6] regularised covariance of every source point (xx xy xz yy yz zz)
+  const double* tgt_cov;   // GICP: [M][6] of every map point (map order)
+  const VgVoxel* vvox;     // VGICP: voxel distributions, same order as vox_start
+  double* maha;            // GICP / VGICP: [correspondence][6] (cov_B + R cov_A R^T)^-1 of the last linearize
   double* partials;     // [workgroups of the round][kPartialStride]
   unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)
 };
@@ -167,6 +187,8 @@ struct KernelParams {
   int32_t lio_rematch;        // LIO: ekfom_data.converge (1: search + plane fit, 0: re-use the stored planes)
   int32_t lio_extrinsic;      // LIO: extrinsic_est_en (columns 6..11 of h_x)
   int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)
+  int32_t coord_mode;         // CoordMode of the target map (GICP / VGICP kernels)
+  double max_corr_sq;         // GICP: corr_dist_threshold_^2 (double, as pcl::Registration holds it)
 };
 
 }  // namespace pcm

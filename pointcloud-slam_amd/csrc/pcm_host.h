@@ -34,7 +34,8 @@ struct TargetMap {   // layout: pcm_device.h
   uint16_t* bpref = nullptr;
   uint32_t* vox_start = nullptr;
   float4* pts = nullptr;
-  GaussVoxel* gvox = nullptr;   // NDT / VGICP models
+  GaussVoxel* gvox = nullptr;   // NDT models
+  uint32_t* order = nullptr;    // input index of every map point (kept on request: GICP covariances are reported in input order)
   uint32_t cap = 0, num_voxels = 0, num_bricks = 0, num_points = 0;
   float res = 0.f, inv_res = 0.f;
   int coord_mode = 0;
@@ -46,14 +47,15 @@ struct TargetMap {   // layout: pcm_device.h
     if (vox_start) hipFree(vox_start);
     if (pts) hipFree(pts);
     if (gvox) hipFree(gvox);
-    gvox = nullptr;
+    if (order) hipFree(order);
+    gvox = nullptr; order = nullptr;
     bricks = nullptr; bmask = nullptr; bpref = nullptr; vox_start = nullptr; pts = nullptr;
     cap = num_voxels = num_bricks = num_points = 0; valid = false;
   }
 };
 
 int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
-                     std::string* err);
+                     std::string* err, bool keep_order = false);
 int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, uint32_t seq0, float4* d_out, std::string* err);
 // batched scan re-ordering (voxel_hash.hip)
 struct SortJob {
@@ -91,6 +93,10 @@ void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* 
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
                          bool write_flags, unsigned char* d_flags_row, double* d_sums);
 void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool d2d, bool trial);
+void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
+// gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
+int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err);
+int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgVoxel* d_out, std::string* err);
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
 
@@ -106,6 +112,16 @@ struct pcm_ctx {
   pcm::TargetMap srcmap;          // NDT D2D: the source's own voxel distributions
   int32_t* corr = nullptr;        // NDT: matched voxel per (element, offset) of the last linearize
   size_t corr_cap = 0;
+  // GICP / VGICP: per-point covariances in MAP order (the source elements are srcmap.pts), voxel distributions, Mahalanobis cache
+  double* src_cov = nullptr;
+  double* tgt_cov = nullptr;
+  size_t src_cov_cap = 0, tgt_cov_cap = 0;
+  bool src_cov_valid = false, tgt_cov_valid = false;
+  int cov_k = 0, cov_reg = -1;
+  pcm::VgVoxel* vvox = nullptr;
+  size_t vvox_cap = 0;
+  double* maha = nullptr;
+  size_t maha_cap = 0;
   float4* src_order = nullptr;   // the scan re-ordered along the world-grid Morton curve (speed only)
   size_t src_order_cap = 0;
   bool src_sorted = false;       // src_order holds the current source

@@ -15,6 +15,7 @@
 // runs (layout: pcm_device.h).
 #include "pcm_device.h"
 #include "pcm_host.h"
+#include "dev_linalg.h"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -29,11 +30,6 @@ __global__ void k_load_points(const char* __restrict__ base, size_t stride, uint
   if (i >= n) return;
   const float* p = reinterpret_cast<const float*>(base + (size_t)i * stride);
   out[i] = make_float4(p[0], p[1], p[2], __uint_as_float(seq0 + i));
-}
-
-__device__ inline int voxel_coord(float v, float res, float inv_res, int mode) {
-  if (mode == COORD_ROUND) return (int)roundf(v * inv_res);  // ivox3d.h:283-286
-  return (int)floorf(v / res - 0.5f);                         // vector3_hash.cuh:35-38
 }
 
 __global__ void k_point_keys(const float4* __restrict__ pts, uint32_t n, float res, float inv_res, int mode,
@@ -177,58 +173,6 @@ __global__ void k_compact_log(const float4* __restrict__ in, const uint32_t* __r
 // order dependent); here a voxel's points are one contiguous run in input order and
 // one lane sums them in double -- deterministic, no atomics.
 // ---------------------------------------------------------------------------
-__device__ inline void eig3_sym_jacobi(const double (&Ain)[9], double (&w)[3], double (&V)[9]) {
-  double A[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) { A[i] = Ain[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 64; sweep++) {
-    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-    const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
-    if (off <= 1e-32 * diag || off == 0.0) break;
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-#pragma unroll
-      for (int q = p + 1; q < 3; q++) {
-        const double apq = A[p * 3 + q];
-        if (apq == 0.0) continue;
-        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const double akp = A[k * 3 + p], akq = A[k * 3 + q];
-          A[k * 3 + p] = c * akp - s * akq;
-          A[k * 3 + q] = s * akp + c * akq;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
-          A[p * 3 + k] = c * apk - s * aqk;
-          A[q * 3 + k] = s * apk + c * aqk;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
-          V[k * 3 + p] = c * vkp - s * vkq;
-          V[k * 3 + q] = s * vkp + c * vkq;
-        }
-      }
-    }
-  }
-  w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      if (j < 2 - i && w[j] > w[j + 1]) {
-        const double t = w[j]; w[j] = w[j + 1]; w[j + 1] = t;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const double u = V[k * 3 + j]; V[k * 3 + j] = V[k * 3 + j + 1]; V[k * 3 + j + 1] = u; }
-      }
-    }
-  }
-}
-
 __global__ void k_gauss_voxels(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, uint32_t nvox, GaussVoxel* __restrict__ out) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
@@ -279,7 +223,7 @@ __global__ void k_gauss_voxels(const float4* __restrict__ pts, const uint32_t* _
 
 // Build the voxel hash of `cloud` into `map`.  One host sync (voxel / brick counts -> array sizes).
 int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
-                     std::string* err) {
+                     std::string* err, bool keep_order) {
   map->release();
   uint32_t n = *n_inout;
   if (n == 0) { *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
@@ -369,7 +313,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
 #undef CK2
       hipFree(keys); hipFree(keys_s); hipFree(idx); hipFree(idx_s); hipFree(vflag); hipFree(vrank); hipFree(d_flags); hipFree(tmp); hipFree(tmp2);
       if (rc2 != PCM_OK) return rc2;
-      return build_target_map(stream, d_pts, n_inout, res, coord_mode, want_gauss, 0u, map, err);   // now within capacity
+      return build_target_map(stream, d_pts, n_inout, res, coord_mode, want_gauss, 0u, map, err, keep_order);   // now within capacity
     }
     uint32_t cap = 1024;
     while (cap < 4ull * nbricks) cap <<= 1;
@@ -396,6 +340,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(stream));
+    if (keep_order) { map->order = idx_s; idx_s = nullptr; }
     map->cap = cap;
     map->num_voxels = nvox;
     map->num_bricks = nbricks;

@@ -99,6 +99,11 @@ class Registration:
     def handle(self):
         return self._h
 
+    @property
+    def config(self):
+        """The object's pcm_config (read-only view; change it through the setters)."""
+        return self._cfg
+
     # -- pcl::Registration / LsqRegistration setters ------------------------
     def set_max_iterations(self, n): self._set(max_iterations=int(n))            # setMaximumIterations
     def set_transformation_epsilon(self, e): self._set(translation_eps=float(e))   # setTransformationEpsilon
@@ -171,6 +176,19 @@ class Registration:
         self._check(self._L.pcm_map_incremental(self._h, C.byref(st), C.c_float(filter_size_map), int(ekf_inited), C.byref(n)))
         return n.value
 
+    def get_covariances(self, target: bool = False) -> np.ndarray:
+        """(N,3,3) regularised covariances of the source (or target) cloud, input order
+        (FastGICP::getSourceCovariances / getTargetCovariances, fast_gicp.hpp:64-70)."""
+        n = C.c_size_t()
+        self._check(self._L.pcm_get_covariances(self._h, int(bool(target)), None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3, 3), np.float64)
+        if n.value:
+            self._check(self._L.pcm_get_covariances(self._h, int(bool(target)), out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def set_correspondence_randomness(self, k): self._set(k_correspondences=int(k))   # setCorrespondenceRandomness  fast_gicp_impl.hpp:61-63
+    def set_regularization_method(self, m): self._set(regularization=m)               # setRegularizationMethod      :66-68
+
     def get_target(self) -> np.ndarray:
         """(M,3) current target points in insertion order."""
         n = C.c_size_t()
@@ -208,6 +226,21 @@ class P2PlaneRegistration(Registration):
     (5-NN in the voxel hash -> plane fit -> n.p+d; laser_mapping.cc:592-701)
     under fast_gicp's GN/LM loop."""
     model = "P2PLANE"
+
+
+class GicpRegistration(Registration):
+    """Generalized ICP with FastGICP's semantics (fast_gicp/include/fast_gicp/gicp/impl/fast_gicp_impl.hpp):
+    20-NN covariances regularised to planes, exact nearest-neighbour correspondences, distribution-to-
+    distribution cost in double.  ``voxel_resolution`` only sizes the search grid (results do not depend on it)."""
+    model = "GICP"
+    defaults = {"voxel_resolution": 0.5}
+
+
+class VgicpRegistration(Registration):
+    """Voxelized GICP with FastVGICP's CPU semantics (impl/fast_vgicp_impl.hpp, fast_vgicp_voxel.hpp):
+    additive voxel distributions at resolution 1.0, DIRECT1 neighbourhood by default (:22-25)."""
+    model = "VGICP"
+    defaults = {"voxel_resolution": 1.0, "num_neighbors": 1}
 
 
 class NdtRegistration(Registration):

@@ -1,0 +1,121 @@
+"""GPU parity of the GICP / VGICP models (kNN covariances, exact NN correspondences, double
+Mahalanobis cost) against the oracle (oracle/orc_gicp.c)."""
+import numpy as np
+import pytest
+
+from helpers import HB_RTOL, POSE_TOL_M, POSE_TOL_RAD, pose_error, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair(synth):
+    return synth.make_pair(3, 8000, 80000)
+
+
+def _both(pcm, model, optimizer, p, **kw):
+    from oracle import Oracle
+    cls = pcm.GicpRegistration if model == "GICP" else pcm.VgicpRegistration
+    g = cls(0, optimizer=optimizer, **kw)
+    cfg = g.config
+    o = Oracle(model, optimizer, voxel_resolution=cfg.voxel_resolution, num_neighbors=cfg.num_neighbors,
+               max_corr_dist=float(cfg.max_corr_dist), k_correspondences=cfg.k_correspondences, regularization=cfg.regularization)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g.set_input_target(p.submap); g.set_input_source(p.scan)
+    return o, g
+
+
+@pytest.mark.parametrize("reg", ["PLANE", "MIN_EIG", "NORMALIZED_MIN_EIG", "FROBENIUS", "NONE"])
+def test_covariances_match_oracle(pcm, pair, reg):
+    """calculate_covariances (fast_gicp_impl.hpp:239-298): exact 20-NN + regularisation, input order."""
+    o, g = _both(pcm, "GICP", "LM", pair, regularization=reg)
+    for target in (False, True):
+        c0 = o.covariances(target)
+        c1 = g.get_covariances(target)
+        assert c1.shape == c0.shape
+        # a distance tie at the k-th neighbour may pick another point; allow a handful of such points
+        bad = np.abs(c1 - c0).reshape(len(c0), -1).max(axis=1) > 1e-9 * max(1.0, np.abs(c0).max())
+        assert bad.sum() <= max(2, len(c0) // 20000), int(bad.sum())
+
+
+def test_covariances_k_and_small_cloud(pcm, synth):
+    """k != 20, and a sparse cloud whose neighbours lie beyond the ring search (brick-table sweep)."""
+    from oracle import Oracle
+    rng = np.random.default_rng(5)
+    cloud = np.zeros((300, 4), np.float32)
+    cloud[:, :3] = rng.uniform(-120, 120, (300, 3))         # ~1 point per 40 m cube: every query needs the sweep
+    cloud[:40, :3] = rng.normal(0, 0.2, (40, 3))            # plus one dense cluster
+    for k in (5, 20, 33):
+        g = pcm.GicpRegistration(0, k_correspondences=k, regularization="MIN_EIG")
+        g.set_input_target(cloud); g.set_input_source(cloud[:50])
+        o = Oracle("GICP", "LM", voxel_resolution=0.5, k_correspondences=k, regularization="MIN_EIG")
+        o.set_input_target(cloud); o.set_input_source(cloud[:50])
+        for target in (False, True):
+            assert np.allclose(g.get_covariances(target), o.covariances(target), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("model,kw", [("GICP", {}), ("GICP", {"max_corr_dist": 0.3}), ("VGICP", {}), ("VGICP", {"num_neighbors": 7}),
+                                      ("VGICP", {"num_neighbors": 27, "voxel_resolution": 0.75})])
+def test_linearize_matches_oracle(pcm, pair, model, kw):
+    p = pair
+    o, g = _both(pcm, model, "LM", p, **kw)
+    for T in (p.guess.astype(np.float64), p.T_gt):
+        c0, H0, b0 = o.linearize(T)
+        c1, H1, b1, inl = g.evaluate_cost(T)
+        assert inl > 0 and abs(inl - o.num_inliers) <= 2      # an exact distance tie / threshold tie may flip a correspondence
+        assert rel_err(H1, H0) < 1e-4 and rel_err(b1, b0) < 1e-4 and abs(c1 - c0) <= 1e-4 * abs(c0)
+        T2 = T.copy(); T2[:3, 3] += [0.02, -0.01, 0.01]     # trial pose on the remembered correspondences / matrices
+        e0 = o.compute_error(T2)
+        assert abs(g.compute_error(T2) - e0) <= 1e-4 * abs(e0)
+
+
+@pytest.mark.parametrize("model,optimizer,kw", [("GICP", "LM", {}), ("GICP", "GN", {"max_corr_dist": 1.0}), ("VGICP", "LM", {}),
+                                                ("VGICP", "GN", {"num_neighbors": 7})])
+def test_align_matches_oracle(pcm, pair, model, optimizer, kw):
+    from oracle.loader import result_T
+    p = pair
+    o, g = _both(pcm, model, optimizer, p, **kw)
+    ro, rg = o.align(p.guess), g.align(p.guess)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+    assert rg.iterations == ro.iterations and rg.converged == bool(ro.converged)
+
+
+def test_gicp_far_source_points_and_batch(pcm, synth):
+    """Scan points far outside the map still get their exact nearest neighbour (FLT_MAX threshold,
+    fast_gicp_impl.hpp:18), and a batch equals the single calls."""
+    from oracle import Oracle
+    pairs = [synth.make_pair(40 + i, 2000 + 500 * i, 20000 + 5000 * i) for i in range(3)]
+    far = pairs[0].scan.copy()
+    far[:200, :3] += np.float32(300.0)                      # 200 points ~500 m away from everything
+    pairs[0].scan[:] = far
+    regs = []
+    for p in pairs:
+        g = pcm.GicpRegistration(0); g.set_input_target(p.submap); g.set_input_source(p.scan); regs.append(g)
+    p = pairs[0]
+    o = Oracle("GICP", "LM", voxel_resolution=0.5, max_corr_dist=float(regs[0].config.max_corr_dist))
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    T = p.guess.astype(np.float64)
+    c0, H0, b0 = o.linearize(T)
+    c1, H1, b1, inl = regs[0].evaluate_cost(T)
+    assert inl == len(p.scan) == o.num_inliers
+    assert rel_err(H1, H0) < 1e-6 and abs(c1 - c0) <= 1e-6 * abs(c0)
+    singles = [g.align(q.guess) for g, q in zip(regs, pairs)]
+    batch = pcm.align_batch(regs, np.stack([q.guess for q in pairs]))
+    for s, b in zip(singles, batch):
+        assert np.array_equal(s.T64, b.T64)
+
+
+def test_gicp_swap_source_and_target(pcm, synth):
+    """swapSourceAndTarget (fast_gicp_impl.hpp:50-58): afterwards the object registers map -> scan."""
+    from oracle import Oracle
+    from oracle.loader import result_T
+    p = synth.make_pair(44, 3000, 12000)
+    g = pcm.GicpRegistration(0); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    o = Oracle("GICP", "LM", voxel_resolution=0.5, max_corr_dist=float(g.config.max_corr_dist))
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g.swap_source_and_target(); o.swap_source_and_target()
+    Tinv = np.linalg.inv(p.guess.astype(np.float64)).astype(np.float32)
+    ro, rg = o.align(Tinv), g.align(Tinv)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
