@@ -52,38 +52,42 @@ static void grid_build(orc_grid *g, const orc_cloud *c, double cell) {
   free(fill); free(pv);
 }
 
+/* insert point pi into the sorted top-k (distance, then index); returns the new count */
+static inline int topk_insert(const orc_cloud *c, const float q[3], int pi, int k, int n, int *idx, float *d2) {
+  const float *p = c->xyz + 3 * (long)pi;
+  const float ex = p[0] - q[0], ey = p[1] - q[1], ez = p[2] - q[2];
+  const float dd = ex * ex + ey * ey + ez * ez;
+  int pos = n < k ? n : k;
+  while (pos > 0 && (dd < d2[pos - 1] || (dd == d2[pos - 1] && pi < idx[pos - 1]))) pos--;
+  if (pos >= k) return n;
+  const int last = n < k ? n : k - 1;
+  for (int t = last; t > pos; t--) { d2[t] = d2[t - 1]; idx[t] = idx[t - 1]; }
+  d2[pos] = dd; idx[pos] = pi;
+  return n < k ? n + 1 : n;
+}
+
 /* exact k nearest neighbours of q (float squared distances like FLANN's L2_Simple<float>);
  * out sorted ascending (distance, then index).  Returns the number found (< k only for tiny clouds). */
 static int grid_knn(const orc_grid *g, const orc_cloud *c, const float q[3], int k, double max_d2, int *idx, float *d2) {
   int key[3], n = 0;
   grid_key(g, q, key);
-  const int RMAX = 64;
-  for (int R = 0; R <= RMAX; R++) {
+  const int RMAX = 12;
+  int exact = 0;
+  for (int R = 0; R <= RMAX && !exact; R++) {
     for (int dx = -R; dx <= R; dx++) for (int dy = -R; dy <= R; dy++) for (int dz = -R; dz <= R; dz++) {
       const int m = abs(dx) > abs(dy) ? abs(dx) : abs(dy);
       if ((m > abs(dz) ? m : abs(dz)) != R) continue;   /* shell only */
       const int v = orc_vhash_find(&g->h, key[0] + dx, key[1] + dy, key[2] + dz);
       if (v < 0) continue;
-      for (int s = g->start[v]; s < g->start[v + 1]; s++) {
-        const int pi = g->pts[s];
-        const float *p = c->xyz + 3 * (long)pi;
-        const float ex = p[0] - q[0], ey = p[1] - q[1], ez = p[2] - q[2];
-        const float dd = ex * ex + ey * ey + ez * ez;
-        /* insert into the sorted top-k (ties: lower index first) */
-        int pos = n < k ? n : k;
-        while (pos > 0 && (dd < d2[pos - 1] || (dd == d2[pos - 1] && pi < idx[pos - 1]))) pos--;
-        if (pos >= k) continue;
-        const int last = n < k ? n : k - 1;
-        for (int t = last; t > pos; t--) { d2[t] = d2[t - 1]; idx[t] = idx[t - 1]; }
-        d2[pos] = dd; idx[pos] = pi;
-        if (n < k) n++;
-      }
+      for (int s = g->start[v]; s < g->start[v + 1]; s++) n = topk_insert(c, q, g->pts[s], k, n, idx, d2);
     }
     /* every unseen point is farther than R * cell from q: exact once the k-th distance is inside, or nothing within max_d2 remains */
     const double reach = (double)R * g->cell;
-    if (n == k && (double)d2[k - 1] <= reach * reach) break;
-    if (reach * reach > max_d2) break;
-    if ((long)(2 * R + 1) * (2 * R + 1) * (2 * R + 1) > 8 * g->ncell + 27 && n >= (c->n < k ? (int)c->n : k)) break;   /* the whole cloud was visited */
+    if ((n == k && (double)d2[k - 1] <= reach * reach) || reach * reach > max_d2) exact = 1;
+  }
+  if (!exact) {   /* sparse neighbourhood: brute force over the cloud */
+    n = 0;
+    for (long i = 0; i < c->n; i++) n = topk_insert(c, q, (int)i, k, n, idx, d2);
   }
   return n;
 }

@@ -221,3 +221,45 @@ def test_ndt_oracle_properties(synth, model):
     # 1 m voxels are coarse and LM may stop on a rejected small step (lsq_registration_impl.hpp:155-158):
     # no accuracy claim, only that the optimiser lowered its own objective
     assert r.converged and o1.linearize(result_T(r))[0] / max(1, o1.num_inliers) < 1.05 * o1.linearize(p.guess.astype(np.float64))[0] / max(1, o1.num_inliers)
+
+
+def test_exact_knn_and_gicp_covariances(synth):
+    """orc_gicp.c: the grid kNN equals brute force (dense and sparse clouds), and the PLANE-regularised
+    covariance has eigenvalues (1e-3, 1, 1) with the small axis along the local surface normal."""
+    from oracle import Oracle
+    p = synth.make_pair(5, 2000, 20000)
+    o = Oracle("GICP", "LM", voxel_resolution=0.5)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    rng = np.random.default_rng(0)
+    sub = p.submap[:, :3]
+    for i in range(40):
+        q = (sub[rng.integers(len(sub))] + rng.normal(0, 0.3 if i < 30 else 40.0, 3)).astype(np.float32)
+        idx, d2 = o.knn_exact(q, 20)
+        d = (sub - q) ** 2
+        dd = (d[:, 0] + d[:, 1]) + d[:, 2]
+        order = np.lexsort((np.arange(len(dd)), dd))[:20]
+        assert (order == idx).all() and np.array_equal(dd[order], d2)
+    cov = o.covariances(target=True)
+    w = np.linalg.eigvalsh(cov[:200])
+    assert np.allclose(w, [1e-3, 1.0, 1.0], rtol=1e-9)
+    ground = np.abs(sub[:, 2]) < 1e-6                     # synthetic ground plane z = 0 -> normal = z
+    if ground.sum() > 50:
+        gi = np.nonzero(ground)[0][:50]
+        interior = [i for i in gi if np.all(np.abs(sub[o.knn_exact(sub[i], 20)[0], 2]) < 1e-6)]
+        for i in interior[:10]:
+            assert abs(cov[i][2, 2] - 1e-3) < 1e-9
+
+
+@pytest.mark.parametrize("model,kw", [("GICP", {}), ("VGICP", {"voxel_resolution": 1.0, "num_neighbors": 1})])
+def test_gicp_oracle_converges(synth, model, kw):
+    from oracle import Oracle
+    from oracle.loader import result_T
+    p = synth.make_pair(3, 4000, 40000)
+    o = Oracle(model, "LM", **kw)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    c_guess = o.linearize(p.guess.astype(np.float64))[0]
+    r = o.align(p.guess)
+    assert r.converged
+    assert o.linearize(result_T(r))[0] < c_guess
+    dt, dr = pose_error(result_T(r), p.T_gt)
+    assert dt < 0.15 and dr < 0.05      # sparse 4k-point scan: a sanity bound, parity is tested on the GPU side
