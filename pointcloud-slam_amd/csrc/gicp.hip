@@ -10,7 +10,7 @@
 //   FastVGICP::linearize / compute_error .. impl/fast_vgicp_impl.hpp:126-204
 // Shape (not a port): the reference walks a FLANN kd-tree per point.  Here the cloud is already
 // grouped by 8x8x8-voxel brick (voxel_hash.hip), so an exact nearest-neighbour query is a scan of
-// the x-slabs of the <= 8 bricks under the query box -- contiguous point runs, no tree -- with an
+// the voxel columns under the query box -- mask word, popcount, contiguous point runs, no tree -- with an
 // exactness test (k-th distance inside the box radius) and one guaranteed-sufficient retry at the
 // radius the first pass proved; queries the map cannot answer within 32 voxels fall back to a
 // pruned sweep of the brick table, so the result is the exact Euclidean kNN in every case.
@@ -27,8 +27,9 @@ namespace {
 
 __device__ inline uint64_t slot_key(const uint4& s) { return ((uint64_t)s.y << 32) | s.x; }
 
-// Visit every map point of the bricks' x-slabs under the box q +- rb.  A point p with
-// |p - q|_inf <= rb lies in a visited slab: the voxel coordinate is monotone in the position.
+// Visit every map point whose voxel lies under the box q +- rb.  A point p with |p - q|_inf <= rb is
+// visited: the voxel coordinate is monotone in the position.  Inside a brick the voxels of one (x, y)
+// column are adjacent bits of one mask word and their points one contiguous run.
 template <class F>
 __device__ inline void scan_box(const TargetView& tg, int mode, const float (&q)[3], float rb, F&& visit) {
   const float lim = (float)(kCoordBias - 64) * tg.res;
@@ -41,7 +42,9 @@ __device__ inline void scan_box(const TargetView& tg, int mode, const float (&q)
   for (int bx = lo[0] >> kBrickShift; bx <= (hi[0] >> kBrickShift); bx++) {
     const int x0 = (lo[0] > bx * 8 ? lo[0] : bx * 8) & 7, x1 = (hi[0] < bx * 8 + 7 ? hi[0] : bx * 8 + 7) & 7;
     for (int by = lo[1] >> kBrickShift; by <= (hi[1] >> kBrickShift); by++) {
+      const int y0 = (lo[1] > by * 8 ? lo[1] : by * 8) & 7, y1 = (hi[1] < by * 8 + 7 ? hi[1] : by * 8 + 7) & 7;
       for (int bz = lo[2] >> kBrickShift; bz <= (hi[2] >> kBrickShift); bz++) {
+        const int z0 = (lo[2] > bz * 8 ? lo[2] : bz * 8) & 7, z1 = (hi[2] < bz * 8 + 7 ? hi[2] : bz * 8 + 7) & 7;
         const uint64_t key = pack_brick(bx, by, bz);
         uint32_t h = hash_coord(bx, by, bz) & tg.mask;
         uint4 s;
@@ -54,13 +57,21 @@ __device__ inline void scan_box(const TargetView& tg, int mode, const float (&q)
           h = (h + 1) & tg.mask;
         }
         if (!found) continue;
-        const uint32_t vs = s.z + gload_u16(&tg.bpref[(size_t)h * 16 + 2 * x0]);
-        const uint32_t ve = x1 == 7 ? s.z + s.w : s.z + gload_u16(&tg.bpref[(size_t)h * 16 + 2 * (x1 + 1)]);
-        const uint32_t ps = gload_u(&tg.vox_start[vs]), pe = gload_u(&tg.vox_start[ve]);
-        for (uint32_t p = ps; p < pe; p++) {
-          const float4 c = gload4(tg.pts + p);
-          const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
-          visit(p, ex * ex + ey * ey + ez * ez);
+        const uint32_t zbits = (1u << (z1 - z0 + 1)) - 1u;
+        for (int x = x0; x <= x1; x++) {
+          for (int y = y0; y <= y1; y++) {
+            const uint32_t w = (uint32_t)(x * 2 + (y >> 2)), sh = (uint32_t)((y & 3) * 8 + z0);
+            const uint32_t m = gload_u(&tg.bmask[(size_t)h * 16 + w]);
+            const uint32_t sel = m & (zbits << sh);
+            if (!sel) continue;
+            const uint32_t vs = s.z + gload_u16(&tg.bpref[(size_t)h * 16 + w]) + (uint32_t)__popc(m & ((1u << sh) - 1u));
+            const uint32_t ps = gload_u(&tg.vox_start[vs]), pe = gload_u(&tg.vox_start[vs + (uint32_t)__popc(sel)]);
+            for (uint32_t p = ps; p < pe; p++) {
+              const float4 c = gload4(tg.pts + p);
+              const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
+              visit(p, ex * ex + ey * ey + ez * ez);
+            }
+          }
         }
       }
     }
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
     if (n < k) n++;
     if (n == k) worst = s_top[(k - 1) * 256 + tid];
   };
-  float r = 2.f * tg.res;
+  float r = tg.res;
   bool exact = false;
   for (;;) {
     n = 0; worst = ~0ull;
