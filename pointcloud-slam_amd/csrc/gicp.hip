@@ -25,6 +25,8 @@ namespace pcm {
 
 namespace {
 
+constexpr uint32_t kSparseBrickVoxels = 24;   // bricks with at most this many occupied voxels are scanned whole
+
 __device__ inline uint64_t slot_key(const uint4& s) { return ((uint64_t)s.y << 32) | s.x; }
 
 // Visit every map point whose voxel lies under the box q +- rb.  A point p with |p - q|_inf <= rb is
@@ -57,6 +59,15 @@ __device__ inline void scan_box(const TargetView& tg, int mode, const float (&q)
           h = (h + 1) & tg.mask;
         }
         if (!found) continue;
+        if (s.w <= kSparseBrickVoxels) {   // sparse brick: its whole point run is cheaper than the column walk
+          const uint4 s2 = gload4u(reinterpret_cast<const uint4*>(&tg.bricks[h]) + 1);   // pt_start, npts
+          for (uint32_t p = s2.x; p < s2.x + s2.y; p++) {
+            const float4 c = gload4(tg.pts + p);
+            const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
+            visit(p, ex * ex + ey * ey + ez * ez);
+          }
+          continue;
+        }
         const uint32_t zbits = (1u << (z1 - z0 + 1)) - 1u;
         for (int x = x0; x <= x1; x++) {
           for (int y = y0; y <= y1; y++) {
@@ -180,32 +191,16 @@ __device__ inline void regularize_cov(int method, const double (&cov)[9], double
 }
 
 // ---------------------------------------------------------------------------
-// k_covariances: one lane per map point, one wave per 64 CONSECUTIVE map points.  The map is
-// brick-major, so the 64 queries of a wave sit in a few neighbouring voxels and want nearly the same
-// candidates: the wave walks the voxel columns under the queries' common box with wave-uniform loops
-// (every candidate is one broadcast load, no per-lane pointer chasing) and each lane keeps its own k
-// best.  A lane is finished when its k-th distance lies inside its margin to the faces of the scanned
-// voxel box (nothing unseen can be closer); otherwise the box grows (res/4 .. 4 res around the
-// queries), and the few lanes still open after that run the per-lane search.
+// k_covariances: one lane per map point (brick-major order: the lanes of a workgroup query
+// neighbouring boxes, so the point runs they scan are shared through L2).
 // dynamic LDS: k x 256 keys
 // ---------------------------------------------------------------------------
-__device__ inline float wave_min_f(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-__device__ inline float wave_max_f(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
-}
-
 __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, int k, int reg, double* __restrict__ out) {
   extern __shared__ uint64_t s_top[];
   const uint32_t tid = threadIdx.x;
   const uint32_t i = blockIdx.x * 256 + tid;
-  const bool active = i < tg.num_points;
-  const float4 pq = gload4(tg.pts + (active ? i : tg.num_points - 1u));
+  if (i >= tg.num_points) return;
+  const float4 pq = gload4(tg.pts + i);
   const float q[3] = {pq.x, pq.y, pq.z};
   int n = 0;
   uint64_t worst = ~0ull;
@@ -223,99 +218,24 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
     if (n < k) n++;
     if (n == k) worst = s_top[(k - 1) * 256 + tid];
   };
-  bool exact = !active;   // lanes past the end take part in the uniform loops only
-  {
-    float bmin[3], bmax[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) { bmin[a] = wave_min_f(q[a]); bmax[a] = wave_max_f(q[a]); }
-    const float lim = (float)(kCoordBias - 64) * tg.res;
-    const float shift = mode == COORD_ROUND ? -0.5f : 0.5f;   // voxel c covers [(c + shift) res, (c + shift + 1) res]
-    int plo[3] = {0, 0, 0}, phi[3] = {-1, -1, -1};
-    const bool finite = isfinite(bmin[0]) && isfinite(bmin[1]) && isfinite(bmin[2]) && isfinite(bmax[0]) && isfinite(bmax[1]) && isfinite(bmax[2]);
-    for (int j = 0; j < 5 && finite; j++) {
-      const float r = tg.res * (0.25f * (float)(1 << j));
-      int lo[3], hi[3];
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        lo[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmin[a] - r, -lim), lim), tg.res, tg.inv_res, mode));
-        hi[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmax[a] + r, -lim), lim), tg.res, tg.inv_res, mode));
-      }
-      if (lo[0] == plo[0] && lo[1] == plo[1] && lo[2] == plo[2] && hi[0] == phi[0] && hi[1] == phi[1] && hi[2] == phi[2]) continue;
-#pragma unroll
-      for (int a = 0; a < 3; a++) { plo[a] = lo[a]; phi[a] = hi[a]; }
-      const int nbricks = ((hi[0] >> 3) - (lo[0] >> 3) + 1) * ((hi[1] >> 3) - (lo[1] >> 3) + 1) * ((hi[2] >> 3) - (lo[2] >> 3) + 1);
-      if (nbricks > 64 || (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) > 1024) break;   // scattered queries: per-lane search
-      if (!exact) { n = 0; worst = ~0ull; }
-      for (int bx = lo[0] >> kBrickShift; bx <= (hi[0] >> kBrickShift); bx++) {
-        const int x0 = (lo[0] > bx * 8 ? lo[0] : bx * 8) & 7, x1 = (hi[0] < bx * 8 + 7 ? hi[0] : bx * 8 + 7) & 7;
-        for (int by = lo[1] >> kBrickShift; by <= (hi[1] >> kBrickShift); by++) {
-          const int y0 = (lo[1] > by * 8 ? lo[1] : by * 8) & 7, y1 = (hi[1] < by * 8 + 7 ? hi[1] : by * 8 + 7) & 7;
-          for (int bz = lo[2] >> kBrickShift; bz <= (hi[2] >> kBrickShift); bz++) {
-            const int z0 = (lo[2] > bz * 8 ? lo[2] : bz * 8) & 7, z1 = (hi[2] < bz * 8 + 7 ? hi[2] : bz * 8 + 7) & 7;
-            const uint64_t key = pack_brick(bx, by, bz);
-            uint32_t h = hash_coord(bx, by, bz) & tg.mask;
-            uint32_t vox_base = 0;
-            bool found = false;
-            for (;;) {
-              const uint4 sl = gload4u(&tg.bricks[h]);
-              const uint64_t sk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)sl.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.x);
-              if (sk == key) { found = true; vox_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl.z); break; }
-              if (sk == kEmptyKey) break;
-              h = (h + 1) & tg.mask;
-            }
-            if (!found) continue;
-            const uint32_t zbits = (1u << (z1 - z0 + 1)) - 1u;
-            for (int x = x0; x <= x1; x++) {
-              for (int y = y0; y <= y1; y++) {
-                const uint32_t w = (uint32_t)(x * 2 + (y >> 2)), sh = (uint32_t)((y & 3) * 8 + z0);
-                const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)gload_u(&tg.bmask[(size_t)h * 16 + w]));
-                const uint32_t sel = m & (zbits << sh);
-                if (!sel) continue;
-                const uint32_t vs = vox_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)gload_u16(&tg.bpref[(size_t)h * 16 + w])) + (uint32_t)__popc(m & ((1u << sh) - 1u));
-                const uint32_t ps = (uint32_t)__builtin_amdgcn_readfirstlane((int)gload_u(&tg.vox_start[vs]));
-                const uint32_t pe = (uint32_t)__builtin_amdgcn_readfirstlane((int)gload_u(&tg.vox_start[vs + (uint32_t)__popc(sel)]));
-                for (uint32_t p = ps; p < pe; p++) {
-                  const float4 c = gload4(tg.pts + p);
-                  const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
-                  if (!exact) visit(p, ex * ex + ey * ey + ez * ez);
-                }
-              }
-            }
-          }
-        }
-      }
-      // margin of this lane to the faces of the scanned voxel box: every unseen point is farther
-      float mg = 3.0e38f;
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const float slack = 1e-4f * tg.res + 4e-6f * fabsf(q[a]);
-        const float wlo = ((float)lo[a] + shift) * tg.res, whi = ((float)hi[a] + shift + 1.f) * tg.res;
-        mg = fminf(mg, fminf(q[a] - wlo, whi - q[a]) - slack);
-      }
-      if (!exact && n == k && mg > 0.f && __uint_as_float((uint32_t)(worst >> 32)) < mg * mg) exact = true;
-      if (__popcll(__ballot(!exact)) <= 4) break;
+  float r = tg.res;
+  bool exact = false;
+  for (;;) {
+    n = 0; worst = ~0ull;
+    scan_box(tg, mode, q, r * 1.0001f, visit);
+    float rn = 2.f * r;
+    if (n == k) {
+      const float d2k = __uint_as_float((uint32_t)(worst >> 32));
+      if (d2k < r * r) { exact = true; break; }
+      rn = sqrtf(d2k) * 1.001f;   // the k points already seen lie inside this radius: the next pass is exact
     }
+    if (rn > 32.f * tg.res) break;
+    r = rn;
   }
-  if (!exact) {   // per-lane search (sparse neighbourhoods, scattered waves)
-    float r = n == k ? sqrtf(__uint_as_float((uint32_t)(worst >> 32))) * 1.001f : 2.f * tg.res;   // the k points already seen lie inside this radius
-    for (;;) {
-      if (r > 32.f * tg.res) break;
-      n = 0; worst = ~0ull;
-      scan_box(tg, mode, q, r * 1.0001f, visit);
-      float rn = 2.f * r;
-      if (n == k) {
-        const float d2k = __uint_as_float((uint32_t)(worst >> 32));
-        if (d2k < r * r) { exact = true; break; }
-        rn = sqrtf(d2k) * 1.001f;
-      }
-      r = rn;
-    }
-    if (!exact) {
-      n = 0; worst = ~0ull;
-      scan_all(tg, mode, q, [&]() { return n == k ? __uint_as_float((uint32_t)(worst >> 32)) : 3.0e38f; }, visit);
-    }
+  if (!exact) {
+    n = 0; worst = ~0ull;
+    scan_all(tg, mode, q, [&]() { return n == k ? __uint_as_float((uint32_t)(worst >> 32)) : 3.0e38f; }, visit);
   }
-  if (!active) return;
   // neighbours (k columns; the mean and the covariance divide by k)  fast_gicp_impl.hpp:254-260
   double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < n; j++) {
