@@ -25,8 +25,6 @@ namespace pcm {
 
 namespace {
 
-constexpr uint32_t kSparseBrickVoxels = 24;   // bricks with at most this many occupied voxels are scanned whole
-
 __device__ inline uint64_t slot_key(const uint4& s) { return ((uint64_t)s.y << 32) | s.x; }
 
 // Visit every map point whose voxel lies under the box q +- rb.  A point p with |p - q|_inf <= rb is
@@ -59,15 +57,6 @@ __device__ inline void scan_box(const TargetView& tg, int mode, const float (&q)
           h = (h + 1) & tg.mask;
         }
         if (!found) continue;
-        if (s.w <= kSparseBrickVoxels) {   // sparse brick: its whole point run is cheaper than the column walk
-          const uint4 s2 = gload4u(reinterpret_cast<const uint4*>(&tg.bricks[h]) + 1);   // pt_start, npts
-          for (uint32_t p = s2.x; p < s2.x + s2.y; p++) {
-            const float4 c = gload4(tg.pts + p);
-            const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
-            visit(p, ex * ex + ey * ey + ez * ez);
-          }
-          continue;
-        }
         const uint32_t zbits = (1u << (z1 - z0 + 1)) - 1u;
         for (int x = x0; x <= x1; x++) {
           for (int y = y0; y <= y1; y++) {
@@ -204,9 +193,18 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
   const float q[3] = {pq.x, pq.y, pq.z};
   int n = 0;
   uint64_t worst = ~0ull;
+#ifdef PCM_COV_STATS
+  uint32_t st_cand = 0, st_pass = 0, st_ins = 0;
+#endif
   auto visit = [&](uint32_t p, float d2) {
     const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | p;
+#ifdef PCM_COV_STATS
+    st_cand++;
+#endif
     if (!(d2 == d2) || (n == k && key >= worst)) return;
+#ifdef PCM_COV_STATS
+    st_ins++;
+#endif
     int pos = n < k ? n : k - 1;
     while (pos > 0) {
       const uint64_t prev = s_top[(pos - 1) * 256 + tid];
@@ -218,12 +216,18 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
     if (n < k) n++;
     if (n == k) worst = s_top[(k - 1) * 256 + tid];
   };
-  float r = tg.res;
+  // first box: a fraction of a voxel (near the sensor one voxel of a scan holds thousands of points and the
+  // k neighbours lie within centimetres); a pass that finds k points proves the radius of the next one,
+  // a pass that finds fewer quadruples it
+  float r = 0.125f * tg.res;
   bool exact = false;
   for (;;) {
     n = 0; worst = ~0ull;
+#ifdef PCM_COV_STATS
+    st_pass++;
+#endif
     scan_box(tg, mode, q, r * 1.0001f, visit);
-    float rn = 2.f * r;
+    float rn = 4.f * r;
     if (n == k) {
       const float d2k = __uint_as_float((uint32_t)(worst >> 32));
       if (d2k < r * r) { exact = true; break; }
@@ -258,6 +262,9 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
   double R[9];
   regularize_cov(reg, cov, R);
   double* o = out + (size_t)i * 6;
+#ifdef PCM_COV_STATS
+  R[0] = st_cand; R[1] = st_pass; R[2] = st_ins; R[4] = exact ? 1.0 : 0.0; R[5] = sqrt((double)__uint_as_float((uint32_t)(worst >> 32)));
+#endif
   gstore_d(o + 0, R[0]); gstore_d(o + 1, R[1]); gstore_d(o + 2, R[2]);
   gstore_d(o + 3, R[4]); gstore_d(o + 4, R[5]); gstore_d(o + 5, R[8]);
 }

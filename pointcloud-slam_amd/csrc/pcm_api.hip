@@ -381,6 +381,11 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     if (rc != PCM_OK) { if (c != c0) c0->err = c->err; return rc; }
     max_n = std::max(max_n, num_elements(c));
   }
+  // GICP / VGICP: the covariance kernels of the contexts were queued on their own streams without a host
+  // sync (they overlap on the device); the batch kernels below run on c0's stream and read their output
+  if (is_gicp(c0->cfg.model)) {
+    for (int i = 0; i < n; i++) HIPCK(c0, hipStreamSynchronize(ctxs[i]->stream));
+  }
   const pcm_config& g = c0->cfg;
   const bool ndt = is_ndt(g.model);
   const bool gicp = is_gicp(g.model);
