@@ -180,31 +180,52 @@ __device__ inline void regularize_cov(int method, const double (&cov)[9], double
 }
 
 // ---------------------------------------------------------------------------
-// k_covariances: one lane per map point (brick-major order: the lanes of a workgroup query
-// neighbouring boxes, so the point runs they scan are shared through L2).
-// dynamic LDS: k x 256 keys
+// k_covariances: one lane per map point, one wave per 64 CONSECUTIVE map points.  The map is
+// brick-major, so the 64 queries of a wave sit in neighbouring voxels and want nearly the same
+// candidates.  Per pass the wave takes the voxel box of its queries grown by r, spreads the box's
+// voxel-column segments over its lanes (one hash probe + mask word + two vox_start words per lane, all
+// 64 in flight together), prefix-sums the run lengths, stages the runs' points into LDS 256 at a time
+// and lets every lane scan the staged points (broadcast LDS reads) into its own k best.  A lane is
+// finished when its k-th distance lies inside its margin to the faces of the scanned box; the next r is
+// the largest radius an unfinished lane has proven (k points seen) or 4 r.  Lanes the box passes cannot
+// finish (r beyond 4 voxels, scattered waves) run the per-lane search.
+// dynamic LDS: k x 256 keys + 4 x (256 staged points + 65 offsets + 64 run starts)
 // ---------------------------------------------------------------------------
+constexpr int kStageCap = 256;
+constexpr int kWaveLds = kStageCap * 16 + 80 * 4 + 64 * 4;   // bytes per wave
+
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ inline float wave_min_f(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ inline float wave_max_f(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, int k, int reg, double* __restrict__ out) {
   extern __shared__ uint64_t s_top[];
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  char* wbase = reinterpret_cast<char*>(s_top + (size_t)k * 256) + (size_t)(tid >> 6) * kWaveLds;
+  float4* st = reinterpret_cast<float4*>(wbase);
+  uint32_t* soff = reinterpret_cast<uint32_t*>(wbase + kStageCap * 16);   // [65] exclusive offsets of the chunk's runs
+  uint32_t* sps = soff + 80;                                              // [64] first point of each run
   const uint32_t i = blockIdx.x * 256 + tid;
-  if (i >= tg.num_points) return;
-  const float4 pq = gload4(tg.pts + i);
+  const bool active = i < tg.num_points;
+  const float4 pq = gload4(tg.pts + (active ? i : tg.num_points - 1u));
   const float q[3] = {pq.x, pq.y, pq.z};
   int n = 0;
   uint64_t worst = ~0ull;
-#ifdef PCM_COV_STATS
-  uint32_t st_cand = 0, st_pass = 0, st_ins = 0;
-#endif
   auto visit = [&](uint32_t p, float d2) {
     const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | p;
-#ifdef PCM_COV_STATS
-    st_cand++;
-#endif
     if (!(d2 == d2) || (n == k && key >= worst)) return;
-#ifdef PCM_COV_STATS
-    st_ins++;
-#endif
     int pos = n < k ? n : k - 1;
     while (pos > 0) {
       const uint64_t prev = s_top[(pos - 1) * 256 + tid];
@@ -216,30 +237,132 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
     if (n < k) n++;
     if (n == k) worst = s_top[(k - 1) * 256 + tid];
   };
-  // first box: a fraction of a voxel (near the sensor one voxel of a scan holds thousands of points and the
-  // k neighbours lie within centimetres); a pass that finds k points proves the radius of the next one,
-  // a pass that finds fewer quadruples it
-  float r = 0.125f * tg.res;
-  bool exact = false;
-  for (;;) {
-    n = 0; worst = ~0ull;
-#ifdef PCM_COV_STATS
-    st_pass++;
-#endif
-    scan_box(tg, mode, q, r * 1.0001f, visit);
-    float rn = 4.f * r;
-    if (n == k) {
-      const float d2k = __uint_as_float((uint32_t)(worst >> 32));
-      if (d2k < r * r) { exact = true; break; }
-      rn = sqrtf(d2k) * 1.001f;   // the k points already seen lie inside this radius: the next pass is exact
+  bool exact = !active;   // lanes past the end only help with the staging
+  {
+    float bmin[3], bmax[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bmin[a] = wave_min_f(q[a]); bmax[a] = wave_max_f(q[a]); }
+    const float lim = (float)(kCoordBias - 64) * tg.res;
+    const float shift = mode == COORD_ROUND ? -0.5f : 0.5f;   // voxel c covers [(c + shift) res, (c + shift + 1) res]
+    const bool finite = isfinite(bmin[0]) && isfinite(bmin[1]) && isfinite(bmin[2]) && isfinite(bmax[0]) && isfinite(bmax[1]) && isfinite(bmax[2]);
+    int plo[3] = {0, 0, 0}, phi[3] = {-1, -1, -1};
+    float r = 0.25f * tg.res;
+    const float rmax = 4.f * tg.res;
+    while (finite && r <= rmax && __ballot(!exact) != 0ull) {
+      int lo[3], hi[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        lo[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmin[a] - r, -lim), lim), tg.res, tg.inv_res, mode));
+        hi[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmax[a] + r, -lim), lim), tg.res, tg.inv_res, mode));
+      }
+      if (lo[0] == plo[0] && lo[1] == plo[1] && lo[2] == plo[2] && hi[0] == phi[0] && hi[1] == phi[1] && hi[2] == phi[2]) { r *= 1.5f; continue; }
+#pragma unroll
+      for (int a = 0; a < 3; a++) { plo[a] = lo[a]; phi[a] = hi[a]; }
+      const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, bz_lo = lo[2] >> kBrickShift, nbz = (hi[2] >> kBrickShift) - bz_lo + 1;
+      if (nx > 64 || ny > 64 || nbz > 8 || nx * ny * nbz > 4096) break;   // scattered queries: per-lane search
+      const int nseg = nx * ny * nbz;
+      if (!exact) { n = 0; worst = ~0ull; }
+      for (int segbase = 0; segbase < nseg; segbase += 64) {
+        // ---- one voxel-column segment (x, y, brick-z) per lane ----
+        const int sg = segbase + (int)lane;
+        uint32_t cnt = 0, ps = 0;
+        if (sg < nseg) {
+          const int ibz = sg % nbz, t2 = sg / nbz, iy = t2 % ny, ix = t2 / ny;
+          const int x = lo[0] + ix, y = lo[1] + iy, bz = bz_lo + ibz;
+          const int z0 = (lo[2] > bz * 8 ? lo[2] : bz * 8) & 7, z1 = (hi[2] < bz * 8 + 7 ? hi[2] : bz * 8 + 7) & 7;
+          const int bx = x >> kBrickShift, by = y >> kBrickShift;
+          const uint64_t key = pack_brick(bx, by, bz);
+          uint32_t h = hash_coord(bx, by, bz) & tg.mask;
+          for (;;) {
+            const uint4 sl = gload4u(&tg.bricks[h]);
+            const uint64_t sk = slot_key(sl);
+            if (sk == key) {
+              const uint32_t w = (uint32_t)((x & 7) * 2 + ((y & 7) >> 2)), sh = (uint32_t)(((y & 7) & 3) * 8 + z0);
+              const uint32_t m = gload_u(&tg.bmask[(size_t)h * 16 + w]);
+              const uint32_t sel = m & (((1u << (z1 - z0 + 1)) - 1u) << sh);
+              if (sel) {
+                const uint32_t vs = sl.z + gload_u16(&tg.bpref[(size_t)h * 16 + w]) + (uint32_t)__popc(m & ((1u << sh) - 1u));
+                ps = gload_u(&tg.vox_start[vs]);
+                cnt = gload_u(&tg.vox_start[vs + (uint32_t)__popc(sel)]) - ps;
+              }
+              break;
+            }
+            if (sk == kEmptyKey) break;
+            h = (h + 1) & tg.mask;
+          }
+        }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t t = __shfl_up(incl, off, 64);
+          if ((int)lane >= off) incl += t;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total == 0u) continue;
+        soff[lane] = incl - cnt;
+        sps[lane] = ps;
+        if (lane == 0) soff[64] = total;
+        wave_sync();
+        // ---- stage the runs' points 256 at a time; every unfinished lane scans them ----
+        for (uint32_t r0 = 0; r0 < total; r0 += kStageCap) {
+          const uint32_t nst = total - r0 < (uint32_t)kStageCap ? total - r0 : (uint32_t)kStageCap;
+          for (uint32_t t = r0 + lane; t < r0 + nst; t += 64) {
+            uint32_t a = 0;   // run of staged point t: the last one whose offset is <= t
+#pragma unroll
+            for (uint32_t step = 32; step >= 1; step >>= 1) { if (soff[a + step] <= t) a += step; }
+            const uint32_t p = sps[a] + (t - soff[a]);
+            float4 c = gload4(tg.pts + p);
+            c.w = __uint_as_float(p);
+            st[t - r0] = c;
+          }
+          wave_sync();
+          if (!exact) {
+            for (uint32_t j = 0; j < nst; j++) {
+              const float4 c = st[j];
+              const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
+              visit(__float_as_uint(c.w), ex * ex + ey * ey + ez * ez);
+            }
+          }
+          wave_sync();
+        }
+      }
+      // margin of this lane to the faces of the scanned voxel box: every unseen point is farther away
+      float mg = 3.0e38f;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float slack = 1e-4f * tg.res + 4e-6f * fabsf(q[a]);
+        const float wlo = ((float)lo[a] + shift) * tg.res, whi = ((float)hi[a] + shift + 1.f) * tg.res;
+        mg = fminf(mg, fminf(q[a] - wlo, whi - q[a]) - slack);
+      }
+      float need = 0.f;
+      if (!exact) {
+        const float d2k = __uint_as_float((uint32_t)(worst >> 32));
+        if (n == k && mg > 0.f && d2k < mg * mg) exact = true;
+        else need = n == k ? sqrtf(d2k) * 1.001f : 4.f * r;   // k points seen: they lie inside this radius
+      }
+      r = fmaxf(wave_max_f(need), 1.25f * r);
     }
-    if (rn > 32.f * tg.res) break;
-    r = rn;
   }
-  if (!exact) {
-    n = 0; worst = ~0ull;
-    scan_all(tg, mode, q, [&]() { return n == k ? __uint_as_float((uint32_t)(worst >> 32)) : 3.0e38f; }, visit);
+  if (!exact) {   // per-lane search (sparse neighbourhoods, scattered waves)
+    float r = n == k ? sqrtf(__uint_as_float((uint32_t)(worst >> 32))) * 1.001f : 2.f * tg.res;
+    for (;;) {
+      if (r > 32.f * tg.res) break;
+      n = 0; worst = ~0ull;
+      scan_box(tg, mode, q, r * 1.0001f, visit);
+      float rn = 2.f * r;
+      if (n == k) {
+        const float d2k = __uint_as_float((uint32_t)(worst >> 32));
+        if (d2k < r * r) { exact = true; break; }
+        rn = sqrtf(d2k) * 1.001f;
+      }
+      r = rn;
+    }
+    if (!exact) {
+      n = 0; worst = ~0ull;
+      scan_all(tg, mode, q, [&]() { return n == k ? __uint_as_float((uint32_t)(worst >> 32)) : 3.0e38f; }, visit);
+    }
   }
+  if (!active) return;
   // neighbours (k columns; the mean and the covariance divide by k)  fast_gicp_impl.hpp:254-260
   double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int j = 0; j < n; j++) {
@@ -262,9 +385,6 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
   double R[9];
   regularize_cov(reg, cov, R);
   double* o = out + (size_t)i * 6;
-#ifdef PCM_COV_STATS
-  R[0] = st_cand; R[1] = st_pass; R[2] = st_ins; R[4] = exact ? 1.0 : 0.0; R[5] = sqrt((double)__uint_as_float((uint32_t)(worst >> 32)));
-#endif
   gstore_d(o + 0, R[0]); gstore_d(o + 1, R[1]); gstore_d(o + 2, R[2]);
   gstore_d(o + 3, R[4]); gstore_d(o + 4, R[5]); gstore_d(o + 5, R[8]);
 }
@@ -483,7 +603,7 @@ TargetView view_of(const TargetMap& m) {
 // regularised kNN covariance of every point of `map` (map order), 6 doubles each
 int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err) {
   if (k < 1 || k > 64) { *err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
-  const size_t lds = sizeof(uint64_t) * 256 * (size_t)k;
+  const size_t lds = sizeof(uint64_t) * 256 * (size_t)k + 4 * (size_t)kWaveLds;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_covariances), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       *err = "cannot reserve LDS for the kNN keys"; return PCM_ERR_HIP;
