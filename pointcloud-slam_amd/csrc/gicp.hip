@@ -14,7 +14,6 @@
 // exactness test (k-th distance inside the box radius) and one guaranteed-sufficient retry at the
 // radius the first pass proved; queries the map cannot answer within 32 voxels fall back to a
 // pruned sweep of the brick table, so the result is the exact Euclidean kNN in every case.
-// The k best candidates of a lane live in LDS as (distance bits << 32 | index) keys.
 // All covariance / Mahalanobis / normal-equation arithmetic is double, as in the reference.
 // Compiled with -ffp-contract=off (see kernels.hip).
 #include "pcm_device.h"
@@ -188,8 +187,8 @@ __device__ inline void regularize_cov(int method, const double (&cov)[9], double
 // and lets every lane scan the staged points (broadcast LDS reads) into its own k best.  A lane is
 // finished when its k-th distance lies inside its margin to the faces of the scanned box; the next r is
 // the largest radius an unfinished lane has proven (k points seen) or 4 r.  Lanes the box passes cannot
-// finish (r beyond 4 voxels, scattered waves) run the per-lane search.
-// dynamic LDS: k x 256 keys + 4 x (256 staged points + 65 offsets + 64 run starts)
+// finish (r beyond 16 voxels, scattered waves) run the per-lane search.
+// dynamic LDS: 4 x (256 staged points + 65 offsets + 64 run starts); the k best of a lane are registers
 // ---------------------------------------------------------------------------
 constexpr int kStageCap = 256;
 constexpr int kWaveLds = kStageCap * 16 + 80 * 4 + 64 * 4;   // bytes per wave
@@ -210,10 +209,11 @@ __device__ inline float wave_max_f(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, int k, int reg, double* __restrict__ out) {
-  extern __shared__ uint64_t s_top[];
+template <int KCAP>
+__global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetView tg, int mode, int k, int reg, double* __restrict__ out) {
+  extern __shared__ uint64_t s_dyn[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  char* wbase = reinterpret_cast<char*>(s_top + (size_t)k * 256) + (size_t)(tid >> 6) * kWaveLds;
+  char* wbase = reinterpret_cast<char*>(s_dyn) + (size_t)(tid >> 6) * kWaveLds;
   float4* st = reinterpret_cast<float4*>(wbase);
   uint32_t* soff = reinterpret_cast<uint32_t*>(wbase + kStageCap * 16);   // [65] exclusive offsets of the chunk's runs
   uint32_t* sps = soff + 80;                                              // [64] first point of each run
@@ -221,34 +221,49 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
   const bool active = i < tg.num_points;
   const float4 pq = gload4(tg.pts + (active ? i : tg.num_points - 1u));
   const float q[3] = {pq.x, pq.y, pq.z};
-  int n = 0;
-  uint64_t worst = ~0ull;
+  // The k best of a lane live in registers, sorted ascending in the LAST k of KCAP slots (the slots in
+  // front hold a -1 sentinel no distance undercuts): the k-th best is always bd[KCAP - 1], and an
+  // insertion is a branch-free shift network -- no LDS round trip per shifted element.
+  float bd[KCAP];
+  uint32_t bi[KCAP];
+  auto reset = [&]() {
+#pragma unroll
+    for (int j = 0; j < KCAP; j++) { bd[j] = j < KCAP - k ? -1.f : 3.0e38f; bi[j] = ~0u; }
+  };
+  reset();
   auto visit = [&](uint32_t p, float d2) {
-    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | p;
-    if (!(d2 == d2) || (n == k && key >= worst)) return;
-    int pos = n < k ? n : k - 1;
-    while (pos > 0) {
-      const uint64_t prev = s_top[(pos - 1) * 256 + tid];
-      if (prev <= key) break;
-      s_top[pos * 256 + tid] = prev;
-      pos--;
+    if (!(d2 < bd[KCAP - 1])) return;   // also rejects NaN; an exact tie with the k-th keeps the earlier point
+    bool c_cur = true;                  // d2 < bd[j] (old value)
+#pragma unroll
+    for (int j = KCAP - 1; j >= 1; j--) {
+      const bool c_prev = d2 < bd[j - 1];
+      bd[j] = c_prev ? bd[j - 1] : (c_cur ? d2 : bd[j]);
+      bi[j] = c_prev ? bi[j - 1] : (c_cur ? p : bi[j]);
+      c_cur = c_prev;
     }
-    s_top[pos * 256 + tid] = key;
-    if (n < k) n++;
-    if (n == k) worst = s_top[(k - 1) * 256 + tid];
+    if (c_cur) { bd[0] = d2; bi[0] = p; }
   };
   bool exact = !active;   // lanes past the end only help with the staging
-  {
+  // A wave whose queries are far apart in space (the brick order jumps) is served in groups of lanes
+  // within 8 voxels of the first pending lane: each group gets its own box passes, the others only help staging.
+  uint64_t pending = __ballot(active);
+  for (int grp = 0; grp < 8 && pending != 0ull; grp++) {
+    const int lead = __ffsll((unsigned long long)pending) - 1;
+    bool mine = active && ((pending >> lane) & 1ull);
+#pragma unroll
+    for (int a = 0; a < 3; a++) mine = mine && fabsf(q[a] - __shfl(q[a], lead, 64)) <= 8.f * tg.res;
+    pending &= ~__ballot(mine);
+    bool gexact = !mine;
     float bmin[3], bmax[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) { bmin[a] = wave_min_f(q[a]); bmax[a] = wave_max_f(q[a]); }
+    for (int a = 0; a < 3; a++) { bmin[a] = wave_min_f(mine ? q[a] : 3.0e38f); bmax[a] = wave_max_f(mine ? q[a] : -3.0e38f); }
     const float lim = (float)(kCoordBias - 64) * tg.res;
     const float shift = mode == COORD_ROUND ? -0.5f : 0.5f;   // voxel c covers [(c + shift) res, (c + shift + 1) res]
     const bool finite = isfinite(bmin[0]) && isfinite(bmin[1]) && isfinite(bmin[2]) && isfinite(bmax[0]) && isfinite(bmax[1]) && isfinite(bmax[2]);
     int plo[3] = {0, 0, 0}, phi[3] = {-1, -1, -1};
     float r = 0.25f * tg.res;
-    const float rmax = 4.f * tg.res;
-    while (finite && r <= rmax && __ballot(!exact) != 0ull) {
+    const float rmax = 16.f * tg.res;
+    while (finite && r <= rmax && __ballot(!gexact) != 0ull) {
       int lo[3], hi[3];
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -261,7 +276,7 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
       const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, bz_lo = lo[2] >> kBrickShift, nbz = (hi[2] >> kBrickShift) - bz_lo + 1;
       if (nx > 64 || ny > 64 || nbz > 8 || nx * ny * nbz > 4096) break;   // scattered queries: per-lane search
       const int nseg = nx * ny * nbz;
-      if (!exact) { n = 0; worst = ~0ull; }
+      if (!gexact) reset();
       for (int segbase = 0; segbase < nseg; segbase += 64) {
         // ---- one voxel-column segment (x, y, brick-z) per lane ----
         const int sg = segbase + (int)lane;
@@ -316,7 +331,7 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
             st[t - r0] = c;
           }
           wave_sync();
-          if (!exact) {
+          if (!gexact) {
             for (uint32_t j = 0; j < nst; j++) {
               const float4 c = st[j];
               const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
@@ -335,49 +350,55 @@ __global__ void __launch_bounds__(256) k_covariances(TargetView tg, int mode, in
         mg = fminf(mg, fminf(q[a] - wlo, whi - q[a]) - slack);
       }
       float need = 0.f;
-      if (!exact) {
-        const float d2k = __uint_as_float((uint32_t)(worst >> 32));
-        if (n == k && mg > 0.f && d2k < mg * mg) exact = true;
-        else need = n == k ? sqrtf(d2k) * 1.001f : 4.f * r;   // k points seen: they lie inside this radius
+      if (!gexact) {
+        const float d2k = bd[KCAP - 1];   // finite <=> k points seen
+        if (mg > 0.f && d2k < mg * mg) gexact = true;
+        else need = d2k < 3.0e38f ? sqrtf(d2k) * 1.001f : 2.f * r;   // k points seen: they lie inside this radius
       }
       r = fmaxf(wave_max_f(need), 1.25f * r);
     }
+    if (mine) exact = gexact;
   }
   if (!exact) {   // per-lane search (sparse neighbourhoods, scattered waves)
-    float r = n == k ? sqrtf(__uint_as_float((uint32_t)(worst >> 32))) * 1.001f : 2.f * tg.res;
+    float r = bd[KCAP - 1] < 3.0e38f ? sqrtf(bd[KCAP - 1]) * 1.001f : 2.f * tg.res;
     for (;;) {
       if (r > 32.f * tg.res) break;
-      n = 0; worst = ~0ull;
+      reset();
       scan_box(tg, mode, q, r * 1.0001f, visit);
       float rn = 2.f * r;
-      if (n == k) {
-        const float d2k = __uint_as_float((uint32_t)(worst >> 32));
-        if (d2k < r * r) { exact = true; break; }
-        rn = sqrtf(d2k) * 1.001f;
+      if (bd[KCAP - 1] < 3.0e38f) {
+        if (bd[KCAP - 1] < r * r) { exact = true; break; }
+        rn = sqrtf(bd[KCAP - 1]) * 1.001f;
       }
       r = rn;
     }
     if (!exact) {
-      n = 0; worst = ~0ull;
-      scan_all(tg, mode, q, [&]() { return n == k ? __uint_as_float((uint32_t)(worst >> 32)) : 3.0e38f; }, visit);
+      reset();
+      scan_all(tg, mode, q, [&]() { return bd[KCAP - 1]; }, visit);
     }
   }
   if (!active) return;
   // neighbours (k columns; the mean and the covariance divide by k)  fast_gicp_impl.hpp:254-260
   double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int j = 0; j < n; j++) {
-    const float4 c = gload4(tg.pts + (uint32_t)s_top[j * 256 + tid]);
-    mean[0] += (double)c.x; mean[1] += (double)c.y; mean[2] += (double)c.z;
+#pragma unroll
+  for (int j = 0; j < KCAP; j++) {
+    if (j >= KCAP - k && bi[j] != ~0u) {
+      const float4 c = gload4(tg.pts + bi[j]);
+      mean[0] += (double)c.x; mean[1] += (double)c.y; mean[2] += (double)c.z;
+    }
   }
 #pragma unroll
   for (int a = 0; a < 3; a++) mean[a] /= (double)k;
-  for (int j = 0; j < n; j++) {
-    const float4 c = gload4(tg.pts + (uint32_t)s_top[j * 256 + tid]);
-    const double d[3] = {(double)c.x - mean[0], (double)c.y - mean[1], (double)c.z - mean[2]};
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
+  for (int j = 0; j < KCAP; j++) {
+    if (j >= KCAP - k && bi[j] != ~0u) {
+      const float4 c = gload4(tg.pts + bi[j]);
+      const double d[3] = {(double)c.x - mean[0], (double)c.y - mean[1], (double)c.z - mean[2]};
 #pragma unroll
-      for (int b = 0; b < 3; b++) cov[a * 3 + b] += d[a] * d[b];
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) cov[a * 3 + b] += d[a] * d[b];
+      }
     }
   }
 #pragma unroll
@@ -603,13 +624,11 @@ TargetView view_of(const TargetMap& m) {
 // regularised kNN covariance of every point of `map` (map order), 6 doubles each
 int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err) {
   if (k < 1 || k > 64) { *err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
-  const size_t lds = sizeof(uint64_t) * 256 * (size_t)k + 4 * (size_t)kWaveLds;
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_covariances), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      *err = "cannot reserve LDS for the kNN keys"; return PCM_ERR_HIP;
-    }
-  }
-  k_covariances<<<(map.num_points + 255) / 256, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
+  const size_t lds = 4 * (size_t)kWaveLds;
+  const dim3 grid((map.num_points + 255) / 256);
+  if (k <= 20) k_covariances<20><<<grid, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
+  else if (k <= 32) k_covariances<32><<<grid, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
+  else k_covariances<64><<<grid, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { *err = std::string("k_covariances: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
   return PCM_OK;
