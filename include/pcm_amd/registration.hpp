@@ -147,6 +147,60 @@ public:
   explicit P2PlaneRegistration(int device = 0) : LsqRegistration<PointSource, PointTarget>(PCM_MODEL_P2PLANE, device) { this->reg_name_ = "pcm_amd::P2PlaneRegistration"; }
 };
 
+// fast_gicp::FastGICP (gicp/fast_gicp.hpp:24-95): setCorrespondenceRandomness, setRegularizationMethod, covariances
+enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };   // gicp_settings.hpp
+enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1 };                               // gicp_settings.hpp
+
+template <typename PointSource, typename PointTarget>
+class GicpRegistration : public LsqRegistration<PointSource, PointTarget> {
+public:
+  explicit GicpRegistration(int device = 0, int model = PCM_MODEL_GICP) : LsqRegistration<PointSource, PointTarget>(model, device) { this->reg_name_ = "pcm_amd::GicpRegistration"; }
+  void setCorrespondenceRandomness(int k) { this->cfg_.k_correspondences = k; }                         // fast_gicp_impl.hpp:61-63
+  void setRegularizationMethod(RegularizationMethod m) {                                                // :66-68
+    static const int map[5] = {PCM_REG_NONE, PCM_REG_MIN_EIG, PCM_REG_NORMALIZED_MIN_EIG, PCM_REG_PLANE, PCM_REG_FROBENIUS};
+    this->cfg_.regularization = map[static_cast<int>(m)];
+  }
+  // getSourceCovariances / getTargetCovariances  fast_gicp.hpp:64-70  (Matrix4d with the 3x3 block set)
+  std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>> getCovariances(bool target) {
+    this->push_config();
+    size_t n = 0;
+    this->check(pcm_get_covariances(this->ctx_, target ? 1 : 0, nullptr, 0, &n), "pcm_get_covariances");
+    std::vector<double> raw(n * 9);
+    this->check(pcm_get_covariances(this->ctx_, target ? 1 : 0, raw.data(), n, &n), "pcm_get_covariances");
+    std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>> out(n, Eigen::Matrix4d::Zero());
+    for (size_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) out[i](a, b) = raw[i * 9 + a * 3 + b];
+    return out;
+  }
+  std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>> getSourceCovariances() { return getCovariances(false); }
+  std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>> getTargetCovariances() { return getCovariances(true); }
+};
+
+// fast_gicp::FastVGICP (gicp/fast_vgicp.hpp): resolution 1.0, DIRECT1, ADDITIVE  (impl/fast_vgicp_impl.hpp:22-25)
+template <typename PointSource, typename PointTarget>
+class VgicpRegistration : public GicpRegistration<PointSource, PointTarget> {
+public:
+  explicit VgicpRegistration(int device = 0) : GicpRegistration<PointSource, PointTarget>(device, PCM_MODEL_VGICP) {
+    this->reg_name_ = "pcm_amd::VgicpRegistration";
+    this->cfg_.voxel_resolution = 1.0f;
+    this->cfg_.num_neighbors = 1;
+  }
+  void setNeighborSearchMethod(NeighborSearchMethod m) { this->cfg_.num_neighbors = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1); }
+};
+
+// fast_gicp::NDTCuda (ndt/ndt_cuda.hpp:21-71): D2D, DIRECT7, resolution 1.0  (cuda/ndt_cuda.cu:15-22)
+enum class NDTDistanceMode { P2D, D2D };
+template <typename PointSource, typename PointTarget>
+class NdtRegistration : public LsqRegistration<PointSource, PointTarget> {
+public:
+  explicit NdtRegistration(int device = 0) : LsqRegistration<PointSource, PointTarget>(PCM_MODEL_NDT_D2D, device) {
+    this->reg_name_ = "pcm_amd::NdtRegistration";
+    this->cfg_.voxel_resolution = 1.0f;
+    this->cfg_.num_neighbors = 7;
+  }
+  void setDistanceMode(NDTDistanceMode m) { this->cfg_.model = m == NDTDistanceMode::P2D ? PCM_MODEL_NDT_P2D : PCM_MODEL_NDT_D2D; }
+  void setNeighborSearchMethod(NeighborSearchMethod m, double /*radius*/ = -1.0) { this->cfg_.num_neighbors = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1); }
+};
+
 }  // namespace pcm_amd
 
 #endif  // __has_include(<pcl/registration/registration.h>)
