@@ -23,6 +23,8 @@
 #include <Eigen/Geometry>
 #include <iostream>
 #include <stdexcept>
+#include <string>
+#include <vector>
 
 #include "../pcm_amd.h"
 
