@@ -48,7 +48,10 @@ typedef enum pcm_model {
   PCM_MODEL_GICP = 1,    /* impl/fast_gicp_impl.hpp:114-237 */
   PCM_MODEL_VGICP = 2,   /* impl/fast_vgicp_impl.hpp:72-204, src/fast_gicp/cuda/compute_derivatives.cu */
   PCM_MODEL_NDT_P2D = 3, /* src/fast_gicp/cuda/ndt_compute_derivatives.cu:33-102 */
-  PCM_MODEL_NDT_D2D = 4  /* src/fast_gicp/cuda/ndt_compute_derivatives.cu:104-175 */
+  PCM_MODEL_NDT_D2D = 4, /* src/fast_gicp/cuda/ndt_compute_derivatives.cu:104-175 */
+  PCM_MODEL_NDT_OMP = 5  /* pclomp::NormalDistributionsTransform: pointcloud_match/ndt_omp/include/pclomp/ndt_omp_impl.hpp:69-880
+                          * (Newton step + More-Thuente line search; max_iterations 35, translation_eps 0.1 = transformation_epsilon_,
+                          *  voxel_resolution 1.0, num_neighbors 7 = DIRECT7 are that class's defaults) */
 } pcm_model;
 
 /* LSQ_OPTIMIZER_TYPE  include/fast_gicp/gicp/lsq_registration.hpp:13 */
@@ -90,7 +93,9 @@ typedef struct pcm_config {
   int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
   int32_t flags;                 /* PCM_FLAG_* (speed / debugging only, never changes a result) */
   int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
-  int32_t reserved[5];
+  float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
+  float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
+  int32_t reserved[3];
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
@@ -210,6 +215,13 @@ int pcm_map_incremental(pcm_ctx *ctx, const pcm_lio_state *state, float filter_s
 
 /* current target points in insertion order (x,y,z per point); *n receives the count (query with out = NULL) */
 int pcm_get_target(pcm_ctx *ctx, float *out_xyz, size_t capacity_points, size_t *n);
+
+/* pclomp NDT (PCM_MODEL_NDT_OMP): one derivatives evaluation at the pose vector p = (x, y, z, roll, pitch, yaw)
+ * exactly as the line search runs it.  pass 0: score + gradient + Hessian (float inner products), pass 1: score +
+ * gradient, pass 2: the double-precision Hessian of computeHessian (uses the angle tables of p as well).
+ * Replaces NormalDistributionsTransform::computeDerivatives / computeHessian
+ * (pointcloud_match/ndt_omp/include/pclomp/ndt_omp_impl.hpp:168-267, 498-559). */
+int pcm_ndt_derivatives(pcm_ctx *ctx, const double p[6], int pass, double *score, double g[6], double H[36]);
 
 /* GICP / VGICP: regularised per-point covariances (row-major 3x3 doubles, INPUT order) of the source
  * (target = 0) or target (target = 1) cloud; computes them if needed.  Query the count with out = NULL.

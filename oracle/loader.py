@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4}
+MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5}
 OPT = {"GN": 0, "LM": 1}
 REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
 
@@ -22,7 +22,8 @@ class OracleConfig(C.Structure):
                 ("voxel_resolution", C.c_double), ("num_neighbors", C.c_int), ("knn", C.c_int),
                 ("min_knn", C.c_int), ("max_range", C.c_double), ("plane_threshold", C.c_double),
                 ("max_corr_dist", C.c_double), ("k_correspondences", C.c_int),
-                ("regularization", C.c_int), ("num_threads", C.c_int), ("map_capacity", C.c_long)]
+                ("regularization", C.c_int), ("num_threads", C.c_int), ("map_capacity", C.c_long),
+                ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double)]
 
 
 class LioState(C.Structure):
@@ -77,6 +78,13 @@ def lib():
         L.orc_test_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_test_voxel_key.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_test_gauss_voxel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_pclndt_derivatives.restype = C.c_double
+        L.orc_pclndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_pclndt_hessian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pclndt_leaf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_pclndt_pose.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pclndt_euler.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_pclndt_svd_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_test_knn_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_test_covariances.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _LIB = L
@@ -170,6 +178,25 @@ class Oracle:
         if n:
             lib().orc_get_target(self._h, out.ctypes.data)
         return out
+
+    # -- pclomp NDT hooks (orc_pclndt.c) ------------------------------------
+    def ndt_derivatives(self, p, compute_hessian=True):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        g = np.zeros(6); H = np.zeros((6, 6))
+        score = lib().orc_pclndt_derivatives(self._h, p.ctypes.data, int(compute_hessian), g.ctypes.data, H.ctypes.data)
+        return score, g, H
+
+    def ndt_hessian(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        H = np.zeros((6, 6))
+        lib().orc_pclndt_hessian(self._h, p.ctypes.data, H.ctypes.data)
+        return H
+
+    def ndt_leaf(self, pt):
+        pt = np.ascontiguousarray(pt, dtype=np.float32)
+        mean = np.zeros(3); icov = np.zeros((3, 3)); n = C.c_int(0)
+        ok = lib().orc_pclndt_leaf(self._h, pt.ctypes.data, mean.ctypes.data, icov.ctypes.data, C.byref(n))
+        return (mean, icov, n.value) if ok else None
 
     def knn_exact(self, q, k):
         q = np.ascontiguousarray(q, dtype=np.float32)

@@ -43,6 +43,7 @@ typedef struct oracle {
   int trace_max, trace_n;
   struct orc_gauss_state *gauss;
   void *gicp;                  /* GICP / VGICP state (orc_gicp.c) */
+  void *pclndt;                /* pclomp NDT state (orc_pclndt.c) */
   struct orc_lru_state *lru;   /* sliding-map state (orc_lru.c) */
   int *nn;                     /* [n_src][5] target indices of the last matching call, -1 = none */
   long nn_cap;
@@ -66,6 +67,11 @@ void orc_gauss_prepare(oracle *o);
 void orc_gauss_invalidate(oracle *o, int target);
 void orc_gauss_swap(oracle *o);
 void orc_gauss_free(oracle *o);
+
+/* orc_pclndt.c */
+int orc_pclndt_align(oracle *o, const float guess[16], orc_result *out);
+void orc_pclndt_invalidate(oracle *o);
+void orc_pclndt_free(oracle *o);
 
 /* orc_gicp.c */
 double orc_gicp_linearize(oracle *o, const double T[16], double *H, double *b);

@@ -47,6 +47,8 @@ void orc_default_config(orc_config *c) {
   c->regularization = ORC_REG_PLANE;    /* fast_gicp_impl.hpp:20 */
   c->num_threads = 0;
   c->map_capacity = 1000000;            /* ivox3d.h:57 */
+  c->ndt_step_size = 0.1;               /* ndt_omp_impl.hpp:48 */
+  c->ndt_outlier_ratio = 0.55;          /* ndt_omp_impl.hpp:48 */
 }
 
 static int orc_threads(const oracle *o) {
@@ -619,6 +621,7 @@ static int step_lm(oracle *o, double x0[16], double delta[16]) {
 /* :52-79 */
 int orc_align(void *h, const float guess[16], orc_result *out) {
   oracle *o = (oracle *)h;
+  if (o->cfg.model == ORC_MODEL_NDT_OMP) return orc_pclndt_align(o, guess, out);   /* orc_pclndt.c */
   if (o->src.n <= 0 || o->tgt.n <= 0) return -1;
   double x0[16];
   for (int i = 0; i < 16; i++) x0[i] = (double)guess[i];
@@ -669,6 +672,7 @@ void orc_destroy(void *h) {
   orc_lru_free(o);
   orc_gauss_free(o);
   orc_gicp_free(o);
+  orc_pclndt_free(o);
   free(o);
 }
 
@@ -679,6 +683,7 @@ int orc_set_target(void *h, const float *xyz, long n, long stride) {
   orc_lru_reset(o);
   orc_gauss_invalidate(o, 1);
   orc_gicp_invalidate(o, 1);
+  orc_pclndt_invalidate(o);
   return 0;
 }
 
@@ -698,6 +703,7 @@ void orc_swap_source_and_target(void *h) {
   orc_lru_reset(o);
   orc_gauss_swap(o);
   orc_gicp_swap(o);
+  orc_pclndt_invalidate(o);
 }
 
 double orc_linearize(void *h, const double T[16], double H[36], double b[6]) {

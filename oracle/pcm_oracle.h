@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-enum { ORC_MODEL_P2PLANE = 0, ORC_MODEL_GICP = 1, ORC_MODEL_VGICP = 2, ORC_MODEL_NDT_P2D = 3, ORC_MODEL_NDT_D2D = 4 };
+enum { ORC_MODEL_P2PLANE = 0, ORC_MODEL_GICP = 1, ORC_MODEL_VGICP = 2, ORC_MODEL_NDT_P2D = 3, ORC_MODEL_NDT_D2D = 4, ORC_MODEL_NDT_OMP = 5 };
 enum { ORC_OPT_GN = 0, ORC_OPT_LM = 1 };
 enum { ORC_REG_NONE = 0, ORC_REG_MIN_EIG = 1, ORC_REG_NORMALIZED_MIN_EIG = 2, ORC_REG_PLANE = 3, ORC_REG_FROBENIUS = 4 };
 
@@ -45,6 +45,8 @@ typedef struct orc_config {
   int regularization;         /* fast_gicp_impl.hpp:20 PLANE */
   int num_threads;
   long map_capacity;          /* ivox3d.h:57 capacity_ 1000000 (0 = unlimited) */
+  double ndt_step_size;       /* ndt_omp_impl.hpp:48 step_size_ 0.1 (More-Thuente maximum step) */
+  double ndt_outlier_ratio;   /* ndt_omp_impl.hpp:48 outlier_ratio_ 0.55 */
 } orc_config;
 
 typedef struct orc_result {
@@ -105,6 +107,14 @@ int orc_test_esti_plane(const float *pts_xyz, int n, float threshold, float plan
 int orc_test_knn(void *h, const float q[3], int *idx_out, float *d2_out);
 long orc_test_voxel_key(void *h, const float p[3], int key[3]);
 int orc_test_gauss_voxel(void *h, const float p[3], float mean[3], float cov[9], int *n);
+/* pclomp NDT (orc_pclndt.c): score, gradient and Hessian at the pose vector p = (t, euler xyz) as the
+ * line search evaluates them; the double-precision Hessian pass; a voxel leaf; small pieces */
+double orc_pclndt_derivatives(void *h, const double p[6], int compute_hessian, double g[6], double H[36]);
+void orc_pclndt_hessian(void *h, const double p[6], double H[36]);
+int orc_pclndt_leaf(void *h, const float pt[3], double mean[3], double icov[9], int *n);
+void orc_pclndt_pose(const double p[6], float T[16]);
+void orc_pclndt_euler(const float R[9], float e[3]);
+void orc_pclndt_svd_solve(const double H[36], const double b[6], double x[6]);
 /* exact k nearest neighbours of q in the target (grid search of orc_gicp.c); returns the count */
 int orc_test_knn_exact(void *h, const float q[3], int k, int *idx, float *d2);
 /* regularised per-point covariances (9 doubles each) of the target (1) or source (0) cloud */

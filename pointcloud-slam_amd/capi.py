@@ -13,14 +13,14 @@ SYMBOLS = [
     "pcm_abi_version", "pcm_default_config", "pcm_create", "pcm_destroy", "pcm_last_error",
     "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
     "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
-    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
+    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_ndt_derivatives", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
 PCM_OK = 0
 PCM_ERR_NOT_CONVERGED = -6
 MEM_HOST, MEM_DEVICE = 0, 1
-MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4}
+MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5}
 OPTIMIZER = {"GN": 0, "LM": 1}
 REGULARIZATION = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
 
@@ -39,7 +39,8 @@ class PcmConfig(C.Structure):
                 ("min_knn", C.c_int32), ("max_range", C.c_float), ("plane_threshold", C.c_float),
                 ("max_corr_dist", C.c_float), ("k_correspondences", C.c_int32),
                 ("regularization", C.c_int32), ("sort_source", C.c_int32), ("flags", C.c_int32),
-                ("map_capacity", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("map_capacity", C.c_int32), ("ndt_step_size", C.c_float), ("ndt_outlier_ratio", C.c_float),
+                ("reserved", C.c_int32 * 3)]
 
 
 class PcmResult(C.Structure):
@@ -123,6 +124,7 @@ def load_library():
     L.pcm_map_incremental.argtypes = [vp, C.POINTER(PcmLioState), C.c_float, i32, C.POINTER(sz)]
     L.pcm_get_target.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.pcm_get_covariances.argtypes = [vp, C.c_int, vp, sz, C.POINTER(sz)]
+    L.pcm_ndt_derivatives.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double), vp, vp]
     L.pcm_align_batch.argtypes = [C.POINTER(vp), i32, vp, vp, vp]
     L.pcm_set_profiling.argtypes = [vp, i32]
     L.pcm_debug_phase_cycles.argtypes = [vp, vp]

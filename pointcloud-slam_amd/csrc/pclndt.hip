@@ -1,0 +1,374 @@
+// pclndt.hip -- pclomp::NormalDistributionsTransform on the brick voxel hash, gfx950.
+//
+// Replaces, for the MI355X path (paths relative to
+// /root/reference/src/pointcloud_match/ndt_omp/include/pclomp):
+//   VoxelGridCovariance::applyFilter (leaf statistics) ... voxel_grid_covariance_omp_impl.hpp:206-368
+//   getNeighborhoodAtPoint{,7,1} .......................... voxel_grid_covariance_omp_impl.hpp:373-442
+//   computeDerivatives + updateDerivatives ................ ndt_omp_impl.hpp:168-267, 451-495
+//   computePointDerivatives (float and double) ............ ndt_omp_impl.hpp:369-448
+//   computeHessian + updateHessian ........................ ndt_omp_impl.hpp:498-590
+// Shape (not a port): the reference keeps a std::map<size_t, Leaf> over a dense linear index,
+// builds it serially (seconds at 10 M points) and stores score, gradient and Hessian of ALL N
+// points (N x 344 B) before summing them serially.  Here the leaves are a payload of the brick
+// hash (built by one radix sort; a voxel's points are one run in input order, summed in double by
+// one lane: deterministic), and a derivatives pass is one streaming kernel: <= 27 leaf lookups per
+// point, the float inner products exactly as updateDerivatives writes them, 43 sums (36 Hessian,
+// 6 gradient, score) accumulated per lane in double and reduced per workgroup, then by one
+// small kernel in fixed order.  The Newton / More-Thuente control flow stays on the host
+// (pclndt_host.h): it is a serial decision per evaluation, one 48-double read-back each.
+// Compiled with -ffp-contract=off.
+#include "pcm_device.h"
+#include "pcm_host.h"
+#include "dev_linalg.h"
+
+namespace pcm {
+
+namespace {
+
+constexpr int kNdtSums = 43;       // 36 H (row-major), 6 gradient, score
+constexpr int kNdtStride = 48;
+
+__device__ inline uint64_t slot_key3(const uint4& s) { return ((uint64_t)s.y << 32) | s.x; }
+
+// leaf index of cell (vx,vy,vz) or -1
+__device__ inline int leaf_lookup(const TargetView& tg, int vx, int vy, int vz) {
+  const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
+  const uint64_t key = pack_brick(bx, by, bz);
+  uint32_t h = hash_coord(bx, by, bz) & tg.mask;
+  uint4 s;
+  for (;;) {
+    s = gload4u(&tg.bricks[h]);
+    const uint64_t sk = slot_key3(s);
+    if (sk == key) break;
+    if (sk == kEmptyKey) return -1;
+    h = (h + 1) & tg.mask;
+  }
+  const uint32_t li = local_index(vx, vy, vz), w = li >> 5, bit = li & 31;
+  const uint32_t m = gload_u(&tg.bmask[(size_t)h * 16 + w]);
+  if (!((m >> bit) & 1u)) return -1;
+  return (int)(s.z + gload_u16(&tg.bpref[(size_t)h * 16 + w]) + (uint32_t)__popc(m & ((1u << bit) - 1u)));
+}
+
+// second pass of applyFilter: one lane per voxel, its points in input order   :206-259, 262-366
+__global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, uint32_t nvox, PclLeaf* __restrict__ out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t p0 = vox_start[v], p1 = vox_start[v + 1];
+  double sum[3] = {0.0, 0.0, 0.0}, sxx[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (uint32_t p = p0; p < p1; p++) {
+    const float4 c = pts[p];
+    const double x[3] = {(double)c.x, (double)c.y, (double)c.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      sum[a] += x[a];
+#pragma unroll
+      for (int b = 0; b < 3; b++) sxx[a * 3 + b] += x[a] * x[b];
+    }
+  }
+  PclLeaf L;
+  int n = (int)(p1 - p0);
+#pragma unroll
+  for (int a = 0; a < 3; a++) L.mean[a] = sum[a] / n;
+#pragma unroll
+  for (int a = 0; a < 9; a++) L.icov[a] = 0.0;
+  if (n >= 6) {   // min_points_per_voxel_  voxel_grid_covariance_omp.h:210
+    double cov[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) cov[a * 3 + b] = (sxx[a * 3 + b] - 2 * (sum[a] * L.mean[b])) / n + L.mean[a] * L.mean[b];   // :323
+    }
+#pragma unroll
+    for (int a = 0; a < 9; a++) cov[a] *= (n - 1.0) / n;                                                                        // :324
+    double sym[9], w[3], V[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) sym[a * 3 + b] = cov[(a > b ? a : b) * 3 + (a > b ? b : a)];   // self-adjoint view: lower triangle
+    }
+    eig3_sym_jacobi(sym, w, V);
+    if (w[0] < 0 || w[1] < 0 || w[2] <= 0) {
+      n = -1;                                                                                       // :331-335
+    } else {
+      const double min_ev = 0.01 * w[2];                                                            // min_covar_eigvalue_mult_  .h:211
+      if (w[0] < min_ev) {                                                                          // :339-349
+        w[0] = min_ev;
+        if (w[1] < min_ev) w[1] = min_ev;
+        double Vi[9], VW[9];
+        inv3<double>(V, Vi);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+          for (int b = 0; b < 3; b++) VW[a * 3 + b] = V[a * 3 + b] * w[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+#pragma unroll
+          for (int b = 0; b < 3; b++) cov[a * 3 + b] = VW[a * 3 + 0] * Vi[0 * 3 + b] + VW[a * 3 + 1] * Vi[1 * 3 + b] + VW[a * 3 + 2] * Vi[2 * 3 + b];
+        }
+      }
+      inv3<double>(cov, L.icov);
+      double mx = -1.7e308, mn = 1.7e308;
+#pragma unroll
+      for (int a = 0; a < 9; a++) { mx = L.icov[a] > mx ? L.icov[a] : mx; mn = L.icov[a] < mn ? L.icov[a] : mn; }
+      if (isinf(mx) || isinf(mn)) n = -1;                                                           // :353-357
+    }
+  }
+  L.n = n;
+  L.pad = 0;
+  out[v] = L;
+}
+
+__device__ inline void ndt_offset3(int nO, int k, int& ox, int& oy, int& oz) {
+  if (nO == 27) { ox = k / 9 - 1; oy = (k / 3) % 3 - 1; oz = k % 3 - 1; return; }   // pcl::getAllNeighborCellIndices order
+  ox = oy = oz = 0;                                                                  // getNeighborhoodAtPoint7  :414-428
+  if (k == 1) ox = 1; else if (k == 2) ox = -1; else if (k == 3) oy = 1; else if (k == 4) oy = -1; else if (k == 5) oz = 1; else if (k == 6) oz = -1;
+}
+
+__device__ inline double wave_sum3(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int NS>
+__device__ inline void block_reduce_store(double (&acc)[NS], double* dst) {
+  __shared__ double s_part[4][kNdtStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const double v = wave_sum3(acc[j]);
+    if (lane == 0) s_part[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) gstore_d(dst + threadIdx.x, ((s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + s_part[2][threadIdx.x]) + s_part[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
+// k_pclndt_derivatives: computeDerivatives with the float inner products of updateDerivatives.
+// grid = blocks, block = 256, `per` points per workgroup
+// ---------------------------------------------------------------------------
+template <bool HESS>
+__global__ void __launch_bounds__(256) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+                                                            double* __restrict__ partials) {
+  const uint32_t begin = blockIdx.x * per;
+  uint32_t end = begin + per;
+  end = end < n ? end : n;
+  double acc[kNdtSums];
+#pragma unroll
+  for (int j = 0; j < kNdtSums; j++) acc[j] = 0.0;
+  const float gauss_d2 = (float)P.gauss_d2;
+  for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+    const float4 p = gload4(src + i);
+    // pcl::transformPointCloud with final_transformation_ (float)
+    float xt[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) xt[a] = P.T[a * 4 + 0] * p.x + (P.T[a * 4 + 1] * p.y + (P.T[a * 4 + 2] * p.z + P.T[a * 4 + 3]));
+    const float fx = floorf(xt[0] / tg.res), fy = floorf(xt[1] / tg.res), fz = floorf(xt[2] / tg.res);   // getNeighborhoodAtPoint  :379-381
+    const float lim = (float)(kCoordBias - 32);
+    if (!(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim)) continue;
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    // computePointDerivatives (float)  :369-412
+    float xj[8], xh[15];
+#pragma unroll
+    for (int r = 0; r < 8; r++) xj[r] = ((P.j_ang[r][0] * p.x + P.j_ang[r][1] * p.y) + P.j_ang[r][2] * p.z) + P.j_ang[r][3] * 0.0f;
+    if (HESS) {
+#pragma unroll
+      for (int r = 0; r < 15; r++) xh[r] = ((P.h_ang[r][0] * p.x + P.h_ang[r][1] * p.y) + P.h_ang[r][2] * p.z) + P.h_ang[r][3] * 0.0f;
+    }
+    // point_gradient4 (4 x 6): identity block + the 8 angular entries; row 3 is zero
+    float pg[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) pg[a][j] = (a == j) ? 1.0f : 0.0f;
+    }
+    pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
+    for (int k = 0; k < P.num_neighbors; k++) {
+      int ox, oy, oz;
+      ndt_offset3(P.num_neighbors, k, ox, oy, oz);
+      const int v = leaf_lookup(tg, cx + ox, cy + oy, cz + oz);
+      if (v < 0) continue;
+      const PclLeaf* L = leaves + v;
+      if (*(const PCM_GLOBAL int32_t*)&L->n < 6) continue;   // nr_points >= min_points_per_voxel_  :396
+      float xt4[3], ci[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) xt4[a] = (float)((double)xt[a] - gload_d(&L->mean[a]));
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) ci[a][b] = (float)gload_d(&L->icov[a * 3 + b]);
+      }
+      // every 4-term float sum of the reference carries a fourth term that is an exact zero (x4[3] = 0, row/column 3 of c_inv4 = 0)
+      float xc[3];   // x_trans4 * c_inv4
+#pragma unroll
+      for (int b = 0; b < 3; b++) xc[b] = ((xt4[0] * ci[0][b] + xt4[1] * ci[1][b]) + xt4[2] * ci[2][b]) + 0.0f;
+      const float q = ((xt4[0] * xc[0] + xt4[1] * xc[1]) + xt4[2] * xc[2]) + 0.0f;
+      float e = expf(-gauss_d2 * q * 0.5f);
+      const float score_inc = (float)(-P.gauss_d1 * (double)e);
+      e = gauss_d2 * e;
+      if (e > 1 || e < 0 || e != e) continue;
+      e = (float)((double)e * P.gauss_d1);
+      acc[42] += (double)score_inc;
+      float cg[3][6];   // c_inv4 * point_gradient4 (row 3 is zero)
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) cg[a][j] = ((ci[a][0] * pg[0][j] + ci[a][1] * pg[1][j]) + ci[a][2] * pg[2][j]) + 0.0f;
+      }
+      float xg[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) xg[j] = ((xt4[0] * cg[0][j] + xt4[1] * cg[1][j]) + xt4[2] * cg[2][j]) + 0.0f;
+#pragma unroll
+      for (int j = 0; j < 6; j++) acc[36 + j] += (double)(e * xg[j]);
+      if (!HESS) continue;
+      float gg[6][6];   // point_gradient4^T * (c_inv4 * point_gradient4)
+#pragma unroll
+      for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) gg[a][j] = ((pg[0][a] * cg[0][j] + pg[1][a] * cg[1][j]) + pg[2][a] * cg[2][j]) + 0.0f;
+      }
+      // point_hessian_ blocks (rows 4i..4i+3): only i = 3, 4, 5 and columns 3, 4, 5 are non-zero  :397-411
+      //   i=3: a b c ; i=4: b d e ; i=5: c e f   with a = (0, xh0, xh1), b = (0, xh2, xh3), c = (0, xh4, xh5), d = (xh6..8), e = (xh9..11), f = (xh12..14)
+      const float va[3] = {0.0f, xh[0], xh[1]}, vb[3] = {0.0f, xh[2], xh[3]}, vc[3] = {0.0f, xh[4], xh[5]}, vd[3] = {xh[6], xh[7], xh[8]}, ve[3] = {xh[9], xh[10], xh[11]},
+                  vf[3] = {xh[12], xh[13], xh[14]};
+#define PCM_XH(v) (((xc[0] * (v)[0] + xc[1] * (v)[1]) + xc[2] * (v)[2]) + 0.0f)
+      const float ha = PCM_XH(va), hb = PCM_XH(vb), hc = PCM_XH(vc), hd = PCM_XH(vd), he = PCM_XH(ve), hf = PCM_XH(vf);
+#undef PCM_XH
+      // x_trans4_x_c_inv4 * block(i): zero for i < 3 and for columns < 3 (a float sum of four exact zeros)
+      const float xh6[6][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, ha, hb, hc}, {0, 0, 0, hb, hd, he}, {0, 0, 0, hc, he, hf}};
+#pragma unroll
+      for (int i2 = 0; i2 < 6; i2++) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) acc[i2 * 6 + j] += (double)(e * ((-gauss_d2 * xg[i2] * xg[j] + xh6[i2][j]) + gg[j][i2]));
+      }
+    }
+  }
+  block_reduce_store<kNdtSums>(acc, partials + (size_t)blockIdx.x * kNdtStride);
+}
+
+// ---------------------------------------------------------------------------
+// k_pclndt_hessian: computeHessian / updateHessian in double  :498-590
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+                                                        double* __restrict__ partials) {
+  const uint32_t begin = blockIdx.x * per;
+  uint32_t end = begin + per;
+  end = end < n ? end : n;
+  double acc[36];
+#pragma unroll
+  for (int j = 0; j < 36; j++) acc[j] = 0.0;
+  for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+    const float4 p = gload4(src + i);
+    float xt[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) xt[a] = P.T[a * 4 + 0] * p.x + (P.T[a * 4 + 1] * p.y + (P.T[a * 4 + 2] * p.z + P.T[a * 4 + 3]));
+    const float fx = floorf(xt[0] / tg.res), fy = floorf(xt[1] / tg.res), fz = floorf(xt[2] / tg.res);
+    const float lim = (float)(kCoordBias - 32);
+    if (!(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim)) continue;
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    const double x[3] = {(double)p.x, (double)p.y, (double)p.z};
+    double pg[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) pg[a][j] = (a == j) ? 1.0 : 0.0;
+    }
+#define PCM_DOT3(v) ((x[0] * (v)[0] + x[1] * (v)[1]) + x[2] * (v)[2])
+    pg[1][3] = PCM_DOT3(P.j_ang_d[0]); pg[2][3] = PCM_DOT3(P.j_ang_d[1]); pg[0][4] = PCM_DOT3(P.j_ang_d[2]); pg[1][4] = PCM_DOT3(P.j_ang_d[3]);
+    pg[2][4] = PCM_DOT3(P.j_ang_d[4]); pg[0][5] = PCM_DOT3(P.j_ang_d[5]); pg[1][5] = PCM_DOT3(P.j_ang_d[6]); pg[2][5] = PCM_DOT3(P.j_ang_d[7]);
+    const double va[3] = {0.0, PCM_DOT3(P.h_ang_d[0]), PCM_DOT3(P.h_ang_d[1])}, vb[3] = {0.0, PCM_DOT3(P.h_ang_d[2]), PCM_DOT3(P.h_ang_d[3])},
+                 vc[3] = {0.0, PCM_DOT3(P.h_ang_d[4]), PCM_DOT3(P.h_ang_d[5])}, vd[3] = {PCM_DOT3(P.h_ang_d[6]), PCM_DOT3(P.h_ang_d[7]), PCM_DOT3(P.h_ang_d[8])},
+                 ve[3] = {PCM_DOT3(P.h_ang_d[9]), PCM_DOT3(P.h_ang_d[10]), PCM_DOT3(P.h_ang_d[11])}, vf[3] = {PCM_DOT3(P.h_ang_d[12]), PCM_DOT3(P.h_ang_d[13]), PCM_DOT3(P.h_ang_d[14])};
+#undef PCM_DOT3
+    for (int k = 0; k < P.num_neighbors; k++) {
+      int ox, oy, oz;
+      ndt_offset3(P.num_neighbors, k, ox, oy, oz);
+      const int v = leaf_lookup(tg, cx + ox, cy + oy, cz + oz);
+      if (v < 0) continue;
+      const PclLeaf* L = leaves + v;
+      if (*(const PCM_GLOBAL int32_t*)&L->n < 6) continue;
+      double xt3[3], ic[9], cxv[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) xt3[a] = (double)xt[a] - gload_d(&L->mean[a]);
+#pragma unroll
+      for (int a = 0; a < 9; a++) ic[a] = gload_d(&L->icov[a]);
+#pragma unroll
+      for (int a = 0; a < 3; a++) cxv[a] = (ic[a * 3 + 0] * xt3[0] + ic[a * 3 + 1] * xt3[1]) + ic[a * 3 + 2] * xt3[2];
+      double e = P.gauss_d2 * exp(-P.gauss_d2 * ((xt3[0] * cxv[0] + xt3[1] * cxv[1]) + xt3[2] * cxv[2]) / 2);
+      if (e > 1 || e < 0 || e != e) continue;
+      e *= P.gauss_d1;
+      double cg[3][6], xg[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) cg[a][j] = (ic[a * 3 + 0] * pg[0][j] + ic[a * 3 + 1] * pg[1][j]) + ic[a * 3 + 2] * pg[2][j];
+        xg[j] = (xt3[0] * cg[0][j] + xt3[1] * cg[1][j]) + xt3[2] * cg[2][j];
+      }
+      // x_trans . (c_inv * point_hessian_.block<3,1>(3i, j)): non-zero for i, j in 3..5 only
+#define PCM_T2(v) ((xt3[0] * ((ic[0] * (v)[0] + ic[1] * (v)[1]) + ic[2] * (v)[2]) + xt3[1] * ((ic[3] * (v)[0] + ic[4] * (v)[1]) + ic[5] * (v)[2])) + xt3[2] * ((ic[6] * (v)[0] + ic[7] * (v)[1]) + ic[8] * (v)[2]))
+      const double ta = PCM_T2(va), tb = PCM_T2(vb), tc = PCM_T2(vc), td = PCM_T2(vd), te = PCM_T2(ve), tf = PCM_T2(vf);
+#undef PCM_T2
+      const double t2[6][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}, {0, 0, 0, ta, tb, tc}, {0, 0, 0, tb, td, te}, {0, 0, 0, tc, te, tf}};
+#pragma unroll
+      for (int i2 = 0; i2 < 6; i2++) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const double t3 = (pg[0][j] * cg[0][i2] + pg[1][j] * cg[1][i2]) + pg[2][j] * cg[2][i2];
+          acc[i2 * 6 + j] += e * ((-P.gauss_d2 * xg[i2] * xg[j] + t2[i2][j]) + t3);
+        }
+      }
+    }
+  }
+  block_reduce_store<36>(acc, partials + (size_t)blockIdx.x * kNdtStride);
+}
+
+// fixed-order sum of the workgroup rows -> one row
+__global__ void __launch_bounds__(1024) k_pclndt_reduce(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+  __shared__ double s_grp[16][kNdtStride];
+  const int j = threadIdx.x & 63, r = threadIdx.x >> 6;   // 16 row groups x 64 columns (48 used)
+  double v = 0.0;
+  if (j < kNdtStride) for (int b = r; b < nblocks; b += 16) v += partials[(size_t)b * kNdtStride + j];
+  if (j < kNdtStride) s_grp[r][j] = v;
+  __syncthreads();
+  if (threadIdx.x < kNdtStride) {
+    double t = 0.0;
+    for (int k = 0; k < 16; k++) t += s_grp[k][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+
+TargetView view_of2(const TargetMap& m) {
+  TargetView v{};
+  v.pts = m.pts; v.vox_start = m.vox_start; v.bricks = m.bricks; v.bmask = m.bmask; v.bpref = m.bpref; v.gvox = m.gvox;
+  v.mask = m.cap - 1; v.num_points = m.num_points; v.inv_res = m.inv_res; v.res = m.res;
+  return v;
+}
+
+}  // namespace
+
+int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err) {
+  k_pclndt_leaves<<<(map.num_voxels + 127) / 128, 128, 0, stream>>>(map.pts, map.vox_start, map.num_voxels, d_out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { *err = std::string("k_pclndt_leaves: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return PCM_OK;
+}
+
+int pclndt_workgroups(uint32_t n, uint32_t* per_out) {
+  uint32_t per = ((n / 1024 + 255) / 256) * 256;
+  per = per < 256 ? 256 : (per > 2048 ? 2048 : per);
+  *per_out = per;
+  return (int)((n + per - 1) / per);
+}
+
+// one derivatives (or Hessian-only) pass; the 48-double result row lands in d_out
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out) {
+  uint32_t per = 0;
+  const int nb = pclndt_workgroups(n, &per);
+  if (pass == 0) k_pclndt_derivatives<true><<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
+  else if (pass == 1) k_pclndt_derivatives<false><<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
+  else k_pclndt_hessian<<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
+  k_pclndt_reduce<<<1, 1024, 0, stream>>>(d_partials, nb, d_out);
+}
+
+}  // namespace pcm

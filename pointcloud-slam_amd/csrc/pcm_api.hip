@@ -8,6 +8,7 @@
 // (SURVEY.md §2.3); here the loop state lives on the device and the host only
 // polls a per-round "pairs still active" counter one round behind the GPU.
 #include "pcm_host.h"
+#include "pclndt_host.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -109,6 +110,7 @@ void free_ws(pcm_ctx* c) {
 
 int coord_mode_for(int model) {
   if (model == PCM_MODEL_P2PLANE || model == PCM_MODEL_GICP) return COORD_ROUND;   // GICP: the grid is only the kNN index, any convention serves
+  if (model == PCM_MODEL_NDT_OMP) return COORD_FLOOR_MUL;
   return model == PCM_MODEL_VGICP ? COORD_FLOOR_HALF_D : COORD_FLOOR_HALF;
 }
 
@@ -118,7 +120,11 @@ bool is_ndt(int model) { return model == PCM_MODEL_NDT_P2D || model == PCM_MODEL
 bool is_gicp(int model) { return model == PCM_MODEL_GICP || model == PCM_MODEL_VGICP; }
 
 int validate_config(pcm_ctx* c, const pcm_config& g) {
-  if (g.model != PCM_MODEL_P2PLANE && !is_ndt(g.model) && !is_gicp(g.model)) { c->err = "unknown registration model"; return PCM_ERR_UNSUPPORTED; }
+  if (g.model != PCM_MODEL_P2PLANE && !is_ndt(g.model) && !is_gicp(g.model) && g.model != PCM_MODEL_NDT_OMP) { c->err = "unknown registration model"; return PCM_ERR_UNSUPPORTED; }
+  if (g.model == PCM_MODEL_NDT_OMP) {
+    if (g.num_neighbors == 19) { c->err = "pclomp NDT neighbourhoods are DIRECT1 / DIRECT7 / DIRECT26 (num_neighbors 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (!(g.ndt_step_size > 0.f) || !(g.ndt_outlier_ratio > 0.f) || !(g.ndt_outlier_ratio < 1.f)) { c->err = "bad ndt_step_size / ndt_outlier_ratio"; return PCM_ERR_INVALID_ARGUMENT; }
+  }
   if ((is_ndt(g.model) || g.model == PCM_MODEL_VGICP) && g.num_neighbors == 19) {
     c->err = "NDT / VGICP neighbourhoods are DIRECT1 / DIRECT7 / DIRECT27 (num_neighbors 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT;
   }
@@ -184,6 +190,33 @@ int prepare(pcm_ctx* c) {
     c->stats.target_voxels = c->map.num_voxels;
     c->stats.target_slots = c->map.cap;
     c->tgt_cov_valid = false;
+    c->pleaf_valid = false;
+  }
+  if (c->cfg.model == PCM_MODEL_NDT_OMP) {
+    // VoxelGridCovariance leaves (NormalDistributionsTransform::init, ndt_omp.h:300-306) + pass buffers
+    if (!c->pleaf_valid) {
+      if (c->pleaf_cap < c->map.num_voxels) {
+        if (c->pleaf) hipFree(c->pleaf);
+        c->pleaf = nullptr; c->pleaf_cap = 0;
+        HIPCK(c, hipMalloc(&c->pleaf, sizeof(PclLeaf) * (size_t)c->map.num_voxels));
+        c->pleaf_cap = c->map.num_voxels;
+      }
+      int rc = build_pclndt_leaves(c->stream, c->map, c->pleaf, &c->err);
+      if (rc != PCM_OK) return rc;
+      c->pleaf_valid = true;
+    }
+    uint32_t per = 0;
+    const size_t need = (size_t)pclndt_workgroups((uint32_t)c->src.n, &per) * 48;
+    if (c->ndt_partials_cap < need) {
+      if (c->ndt_partials) hipFree(c->ndt_partials);
+      c->ndt_partials = nullptr; c->ndt_partials_cap = 0;
+      HIPCK(c, hipMalloc(&c->ndt_partials, sizeof(double) * need));
+      HIPCK(c, hipMemsetAsync(c->ndt_partials, 0, sizeof(double) * need, c->stream));
+      c->ndt_partials_cap = need;
+    }
+    if (!c->ndt_out) HIPCK(c, hipMalloc(&c->ndt_out, sizeof(double) * 48));
+    if (!c->ndt_out_host) HIPCK(c, hipHostMalloc(&c->ndt_out_host, sizeof(double) * 48));
+    return PCM_OK;
   }
   if (gicp) {
     // FastGICP::computeTransformation: covariances of both clouds, lazily   fast_gicp_impl.hpp:102-110
@@ -232,6 +265,10 @@ int prepare(pcm_ctx* c) {
     const size_t ncorr = c->src.n * (size_t)(c->cfg.model == PCM_MODEL_VGICP ? c->cfg.num_neighbors : 1);
     if (c->maha_cap < ncorr) {
       if (c->maha) hipFree(c->maha);
+    if (c->pleaf) hipFree(c->pleaf);
+    if (c->ndt_partials) hipFree(c->ndt_partials);
+    if (c->ndt_out) hipFree(c->ndt_out);
+    if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
       c->maha = nullptr; c->maha_cap = 0;
       HIPCK(c, hipMalloc(&c->maha, sizeof(double) * 6 * ncorr));
       c->maha_cap = ncorr;
@@ -513,6 +550,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
 
 // one LINEARIZE or TRIAL pass at a caller-supplied pose (parity hook)
 int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPartialStride]) {
+  if (c->cfg.model == PCM_MODEL_NDT_OMP) { c->err = "the pclomp NDT model is evaluated through pcm_ndt_derivatives"; return PCM_ERR_UNSUPPORTED; }
   int rc = prepare(c);
   if (rc != PCM_OK) return rc;
   const bool ndt = is_ndt(c->cfg.model);
@@ -543,6 +581,57 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   return PCM_OK;
 }
 
+// one pclomp NDT pass on the device: launch, read the 48-double row back (pass 0/1: H, g, score; pass 2: H)
+int pclndt_eval(pcm_ctx* c, int pass, const NdtOmpParams& P, ndtomp::Eval* e) {
+  launch_pclndt_pass(c->stream, c->map, c->pleaf, c->src.d_pts, (uint32_t)c->src.n, P, pass, c->ndt_partials, c->ndt_out);
+  HIPCK(c, hipGetLastError());
+  HIPCK(c, hipMemcpyAsync(c->ndt_out_host, c->ndt_out, sizeof(double) * 48, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(e->H, c->ndt_out_host, sizeof(double) * 36);
+  if (pass != 2) {
+    std::memcpy(e->g, c->ndt_out_host + 36, sizeof(double) * 6);
+    e->score = c->ndt_out_host[42];
+  }
+  c->stats.linearize_launches += 1;
+  c->stats.point_passes += c->src.n;
+  return PCM_OK;
+}
+
+auto make_ndt_solver(pcm_ctx* c) {
+  auto ev = [c](int pass, const NdtOmpParams& P, ndtomp::Eval* e) { return pclndt_eval(c, pass, P, e); };
+  ndtomp::Solver<decltype(ev)> s{ev};
+  s.step_size = (double)c->cfg.ndt_step_size;
+  s.eps = c->cfg.translation_eps;            // transformation_epsilon_
+  s.outlier_ratio = (double)c->cfg.ndt_outlier_ratio;
+  s.resolution = c->cfg.voxel_resolution;
+  s.max_iterations = c->cfg.max_iterations;
+  s.num_neighbors = c->cfg.num_neighbors;
+  return s;
+}
+
+// pclomp::NormalDistributionsTransform::computeTransformation  (ndt_omp_impl.hpp:69-156)
+int pclndt_align(pcm_ctx* c, const float guess[16], pcm_result* out) {
+  int rc = prepare(c);
+  if (rc != PCM_OK) return rc;
+  auto solver = make_ndt_solver(c);
+  ndtomp::Eval last{};
+  int iters = 0, conv = 0;
+  float g16[16];
+  std::memcpy(g16, guess, sizeof(g16));
+  rc = solver.align(g16, &last, &iters, &conv);
+  if (rc != PCM_OK) return rc;
+  std::memset(out, 0, sizeof(*out));
+  for (int i = 0; i < 16; i++) { out->T[i] = solver.P.T[i]; out->T64[i] = (double)solver.P.T[i]; }
+  std::memcpy(out->H, last.H, sizeof(out->H));   // hessian_eigen_
+  out->cost = last.score;                        // trans_probability_ * N
+  out->iterations = iters;
+  out->converged = conv;
+  out->num_linearize = solver.n_deriv;
+  out->num_compute_error = solver.n_hess;
+  out->status = PCM_OK;
+  return PCM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -570,6 +659,8 @@ void pcm_default_config(pcm_config* cfg) {
   cfg->regularization = PCM_REG_PLANE;
   cfg->sort_source = 1;
   cfg->map_capacity = 1000000;   // IVox Options::capacity_  ivox3d.h:57
+  cfg->ndt_step_size = 0.1f;     // ndt_omp_impl.hpp:48
+  cfg->ndt_outlier_ratio = 0.55f;
 }
 
 pcm_ctx* pcm_create(int device, const pcm_config* cfg) {
@@ -608,6 +699,10 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->tgt_cov) hipFree(c->tgt_cov);
     if (c->vvox) hipFree(c->vvox);
     if (c->maha) hipFree(c->maha);
+    if (c->pleaf) hipFree(c->pleaf);
+    if (c->ndt_partials) hipFree(c->ndt_partials);
+    if (c->ndt_out) hipFree(c->ndt_out);
+    if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
     if (c->planes) hipFree(c->planes);
     if (c->counter) hipFree(c->counter);
     if (c->nn) hipFree(c->nn);
@@ -721,8 +816,35 @@ int pcm_align(pcm_ctx* c, const float guess[16], pcm_result* out) {
   if (!guess || !out) return PCM_ERR_INVALID_ARGUMENT;
   int rc = validate_config(c, c->cfg);
   if (rc != PCM_OK) return rc;
+  if (c->cfg.model == PCM_MODEL_NDT_OMP) return pclndt_align(c, guess, out);
   pcm_ctx* arr[1] = {c};
   return align_batch_impl(arr, 1, guess, out, nullptr);
+}
+
+// pclomp NDT: score, gradient, Hessian at the pose vector p = (x, y, z, roll, pitch, yaw) exactly as the line search
+// evaluates them (computeDerivatives, ndt_omp_impl.hpp:168-267); pass 2 = computeHessian (:498-559) with the angle
+// tables of the previous call
+int pcm_ndt_derivatives(pcm_ctx* c, const double p[6], int pass, double* score, double g[6], double H[36]) {
+  CHECK_CTX(c);
+  if (!p || pass < 0 || pass > 2) return PCM_ERR_INVALID_ARGUMENT;
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  if (c->cfg.model != PCM_MODEL_NDT_OMP) { c->err = "pcm_ndt_derivatives needs the NDT_OMP model"; return PCM_ERR_UNSUPPORTED; }
+  rc = prepare(c);
+  if (rc != PCM_OK) return rc;
+  auto solver = make_ndt_solver(c);
+  solver.gauss_params();
+  double pp[6];
+  std::memcpy(pp, p, sizeof(pp));
+  solver.set_pose(pp);
+  solver.angle_derivatives(pp);
+  ndtomp::Eval e{};
+  rc = pclndt_eval(c, pass, solver.P, &e);
+  if (rc != PCM_OK) return rc;
+  if (score) *score = e.score;
+  if (g) std::memcpy(g, e.g, sizeof(e.g));
+  if (H) std::memcpy(H, e.H, sizeof(e.H));
+  return PCM_OK;
 }
 
 int pcm_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_result* host_out, void* device_out) {
@@ -731,6 +853,19 @@ int pcm_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resul
     CHECK_CTX(ctxs[i]);
     int rc = validate_config(ctxs[i], ctxs[i]->cfg);
     if (rc != PCM_OK) return rc;
+  }
+  if (ctxs[0]->cfg.model == PCM_MODEL_NDT_OMP) {
+    // the Newton / line-search control flow of pclomp NDT is per object (a host decision per evaluation): no lock-step batch
+    std::vector<pcm_result> res((size_t)n);
+    int worst = PCM_OK;
+    for (int i = 0; i < n; i++) {
+      if (ctxs[i]->cfg.model != PCM_MODEL_NDT_OMP) { ctxs[0]->err = "all contexts of a batch must share the model"; return PCM_ERR_INVALID_ARGUMENT; }
+      const int rc = pclndt_align(ctxs[i], guesses + 16 * (size_t)i, &res[i]);
+      if (rc != PCM_OK) { ctxs[0]->err = ctxs[i]->err; worst = rc; res[i].status = rc; }
+    }
+    if (host_out) std::memcpy(host_out, res.data(), sizeof(pcm_result) * (size_t)n);
+    if (device_out && hipMemcpy(device_out, res.data(), sizeof(pcm_result) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return PCM_ERR_HIP;
+    return worst;
   }
   return align_batch_impl(ctxs, n, guesses, host_out, device_out);
 }

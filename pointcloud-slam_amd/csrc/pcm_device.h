@@ -75,12 +75,14 @@ static_assert(sizeof(GaussVoxel) == 48, "GaussVoxel must be 48 bytes");
 enum CoordMode : int32_t {
   COORD_ROUND = 0,       // iVox Pos2Grid: round(p * inv_res)          jueying_lio/include/ivox3d/ivox3d.h:283-286
   COORD_FLOOR_HALF = 1,  // fast_gicp CUDA: floor(p / res - 0.5), float  include/fast_gicp/cuda/vector3_hash.cuh:35-38
-  COORD_FLOOR_HALF_D = 2 // fast_gicp CPU VGICP: the same in double     include/fast_gicp/gicp/fast_vgicp_voxel.hpp:158-160
+  COORD_FLOOR_HALF_D = 2,// fast_gicp CPU VGICP: the same in double     include/fast_gicp/gicp/fast_vgicp_voxel.hpp:158-160
+  COORD_FLOOR_MUL = 3    // pclomp VoxelGridCovariance build: floor(p * inverse_leaf_size)   ndt_omp/include/pclomp/voxel_grid_covariance_omp_impl.hpp:220-222
 };
 
 __host__ __device__ inline int voxel_coord(float v, float res, float inv_res, int mode) {
   if (mode == COORD_ROUND) return (int)roundf(v * inv_res);
   if (mode == COORD_FLOOR_HALF) return (int)floorf(v / res - 0.5f);
+  if (mode == COORD_FLOOR_MUL) return (int)floorf(v * inv_res);
   return (int)floor((double)v / (double)res - 0.5);
 }
 
@@ -92,6 +94,16 @@ struct VgVoxel {
   int32_t pad;
 };
 static_assert(sizeof(VgVoxel) == 80, "VgVoxel must be 80 bytes");
+
+// pclomp VoxelGridCovariance::Leaf as the NDT derivatives read it (mean_, icov_, nr_points; doubles)
+// ndt_omp/include/pclomp/voxel_grid_covariance_omp.h:90-190
+struct PclLeaf {
+  double mean[3];
+  double icov[9];
+  int32_t n;        // nr_points; -1 when the covariance was rejected (impl :331-335, 353-357)
+  int32_t pad;
+};
+static_assert(sizeof(PclLeaf) == 104, "PclLeaf must be 104 bytes");
 
 // Explicit global-address-space accessors.  Pointers that reach a kernel through a
 // descriptor struct are generic to the compiler; a generic (flat) load counts on
@@ -121,6 +133,18 @@ __device__ inline void gstore_f(float* p, float v) { *(PCM_GLOBAL float*)p = v; 
 __device__ inline void gstore_d(double* p, double v) { *(PCM_GLOBAL double*)p = v; }
 __device__ inline double gload_d(const double* p) { return *(const PCM_GLOBAL double*)p; }
 #endif
+
+// pose-dependent constants of one pclomp NDT derivatives pass (kernel argument, filled on the host by pclndt_host.h)
+struct NdtOmpParams {
+  float T[16];            // final_transformation_ (row-major)
+  float j_ang[8][4];      // computeAngleDerivatives, float matrix   ndt_omp_impl.hpp:308-317
+  float h_ang[16][4];     // :339-364
+  double j_ang_d[8][3];   // double vectors j_ang_a_ .. j_ang_h_      :298-306
+  double h_ang_d[15][3];  // h_ang_a2_ .. h_ang_f3_                   :319-337
+  double gauss_d1, gauss_d2;
+  int32_t num_neighbors;  // 1, 7 or 27
+  int32_t pad;
+};
 
 struct TargetView {
   const float4* pts;

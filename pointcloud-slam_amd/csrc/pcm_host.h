@@ -97,6 +97,10 @@ void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
 int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err);
 int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgVoxel* d_out, std::string* err);
+// pclndt.hip: pclomp NDT leaves and derivative passes (pass 0: score+gradient+Hessian, 1: score+gradient, 2: double Hessian only)
+int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err);
+int pclndt_workgroups(uint32_t n, uint32_t* per_out);
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out);
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
 
@@ -122,6 +126,14 @@ struct pcm_ctx {
   size_t vvox_cap = 0;
   double* maha = nullptr;
   size_t maha_cap = 0;
+  // pclomp NDT: leaf payload of the map, partial rows, result row (device + pinned host)
+  pcm::PclLeaf* pleaf = nullptr;
+  size_t pleaf_cap = 0;
+  bool pleaf_valid = false;
+  double* ndt_partials = nullptr;
+  size_t ndt_partials_cap = 0;
+  double* ndt_out = nullptr;
+  double* ndt_out_host = nullptr;
   float4* src_order = nullptr;   // the scan re-ordered along the world-grid Morton curve (speed only)
   size_t src_order_cap = 0;
   bool src_sorted = false;       // src_order holds the current source

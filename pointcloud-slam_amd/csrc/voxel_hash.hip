@@ -233,7 +233,8 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   void *tmp = nullptr, *tmp2 = nullptr;
   size_t tmp_bytes = 0, tmp2_bytes = 0;
   int rc = PCM_OK;
-  const float inv_res = (float)(1.0 / res);  // ivox3d.h:67  inv_resolution_ = 1.0 / resolution_ (float)
+  // ivox3d.h:67  inv_resolution_ = 1.0 / resolution_ (float);  pcl::VoxelGrid: inverse_leaf_size_ = 1 / leaf_size_ in float
+  const float inv_res = coord_mode == COORD_FLOOR_MUL ? 1.0f / res : (float)(1.0 / res);
 #define CK(x)                                                                    \
   do {                                                                           \
     hipError_t e_ = (x);                                                         \

@@ -176,6 +176,15 @@ class Registration:
         self._check(self._L.pcm_map_incremental(self._h, C.byref(st), C.c_float(filter_size_map), int(ekf_inited), C.byref(n)))
         return n.value
 
+    def ndt_derivatives(self, p, hessian="float"):
+        """pclomp NDT: (score, gradient, Hessian) at the pose vector p = (x, y, z, roll, pitch, yaw)
+        (computeDerivatives, ndt_omp_impl.hpp:168-267); hessian = "float" | None | "double" (computeHessian :498-559)."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        g = np.zeros(6); H = np.zeros((6, 6)); score = C.c_double()
+        mode = {"float": 0, None: 1, "double": 2}[hessian]
+        self._check(self._L.pcm_ndt_derivatives(self._h, p.ctypes.data, mode, C.byref(score), g.ctypes.data, H.ctypes.data))
+        return score.value, g, H
+
     def get_covariances(self, target: bool = False) -> np.ndarray:
         """(N,3,3) regularised covariances of the source (or target) cloud, input order
         (FastGICP::getSourceCovariances / getTargetCovariances, fast_gicp.hpp:64-70)."""
@@ -241,6 +250,17 @@ class VgicpRegistration(Registration):
     additive voxel distributions at resolution 1.0, DIRECT1 neighbourhood by default (:22-25)."""
     model = "VGICP"
     defaults = {"voxel_resolution": 1.0, "num_neighbors": 1}
+
+
+class PclNdtRegistration(Registration):
+    """pclomp::NormalDistributionsTransform (pointcloud_match/ndt_omp/include/pclomp/ndt_omp_impl.hpp):
+    Newton step with the analytic Hessian + More-Thuente line search on VoxelGridCovariance leaves;
+    defaults of that class: resolution 1.0, step 0.1, outlier ratio 0.55, epsilon 0.1, 35 iterations, DIRECT7 (:48,60-63)."""
+    model = "NDT_OMP"
+    defaults = {"voxel_resolution": 1.0, "num_neighbors": 7, "max_iterations": 35, "translation_eps": 0.1}
+
+    def set_step_size(self, s): self._set(ndt_step_size=float(s))                  # setStepSize       ndt_omp.h
+    def set_outlier_ratio(self, r): self._set(ndt_outlier_ratio=float(r))          # setOulierRatio    ndt_omp.h
 
 
 class NdtRegistration(Registration):

@@ -264,3 +264,84 @@ def test_gicp_oracle_converges(synth, model, kw):
     dt, dr = pose_error(result_T(r), p.T_gt)
     if model == "GICP":
         assert dt < 0.15 and dr < 0.05      # sparse 4k-point scan: a sanity bound, parity is tested on the GPU side
+
+
+def _blob_scene(seed=1):
+    """Gaussian blobs at voxel centres (1 m grid) + source points well inside the voxels: the NDT score is
+    smooth there (no point changes voxel under a 1e-4 perturbation), so finite differences are meaningful."""
+    rng = np.random.default_rng(seed)
+    centers = np.unique(rng.integers(-5, 6, (60, 3)).astype(np.float64) + 0.5, axis=0)
+    tgt = np.concatenate([c + rng.normal(0, [0.12, 0.08, 0.03], (40, 3)) @ np.linalg.qr(rng.normal(size=(3, 3)))[0].T for c in centers]).astype(np.float32)
+    src = (centers[rng.integers(len(centers), size=400)] + rng.uniform(-0.15, 0.15, (400, 3))).astype(np.float32)
+    return tgt, src
+
+
+@pytest.mark.parametrize("nn", [1, 7, 27])
+def test_pclndt_oracle_derivatives_are_derivatives(nn):
+    """orc_pclndt.c: gradient = d(score)/dp and Hessian = d(gradient)/dp (eq. 6.12 / 6.13) by central
+    differences; the float-path Hessian equals the double-path one up to float rounding."""
+    from oracle import Oracle
+    tgt, src = _blob_scene()
+    o = Oracle("NDT_OMP", "LM", voxel_resolution=1.0, num_neighbors=nn, translation_eps=0.1, max_iterations=35, num_threads=4)
+    o.set_input_target(tgt); o.set_input_source(src)
+    p = np.array([0.02, -0.03, 0.01, 0.004, -0.006, 0.005])
+    s0, g, H = o.ndt_derivatives(p)
+    Hd = o.ndt_hessian(p)
+    num = np.zeros(6); Hn = np.zeros((6, 6))
+    for i in range(6):
+        d = np.zeros(6); d[i] = 1e-4
+        sp, gp, _ = o.ndt_derivatives(p + d); sm, gm, _ = o.ndt_derivatives(p - d)
+        num[i] = (sp - sm) / 2e-4; Hn[:, i] = (gp - gm) / 2e-4
+    assert s0 > 0
+    assert np.abs(g - num).max() < 1e-3 * np.abs(g).max()
+    assert np.abs(Hd - Hn).max() < 1e-3 * np.abs(Hd).max()
+    assert np.abs(H - Hd).max() < 1e-4 * np.abs(Hd).max()
+
+
+def test_pclndt_oracle_pieces():
+    """Leaf statistics vs numpy (unbiased covariance, eigenvalue inflation to 1 % of the largest, inverse),
+    the Euler / pose round trip, and the SVD solve vs numpy."""
+    from oracle import Oracle
+    from oracle.loader import lib
+    tgt, src = _blob_scene(3)
+    o = Oracle("NDT_OMP", "LM", voxel_resolution=1.0, num_neighbors=7)
+    o.set_input_target(tgt); o.set_input_source(src)
+    key = np.floor(tgt[:, :3] * np.float32(1.0)).astype(int)
+    for c in np.unique(key, axis=0)[:20]:
+        pts = tgt[(key == c).all(axis=1), :3].astype(np.float64)
+        leaf = o.ndt_leaf((c + 0.5).astype(np.float32))
+        assert leaf is not None and leaf[2] == len(pts)
+        if len(pts) < 6:
+            continue
+        assert np.allclose(leaf[0], pts.mean(axis=0), atol=1e-12)
+        cov = np.cov(pts.T, bias=True) * (len(pts) - 1.0) / len(pts)      # :323-324: biased estimate times (n-1)/n
+        w, V = np.linalg.eigh(cov)
+        w = np.maximum(w, 0.01 * w[2])
+        assert np.allclose(leaf[1], np.linalg.inv(V @ np.diag(w) @ V.T), rtol=1e-6)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        p = np.concatenate([rng.uniform(-5, 5, 3), rng.uniform(-1.2, 1.2, 3)])
+        T = np.zeros(16, np.float32); lib().orc_pclndt_pose(p.ctypes.data, T.ctypes.data)
+        T = T.reshape(4, 4)
+        assert np.allclose(T[:3, :3], Rotation.from_euler("XYZ", p[3:]).as_matrix(), atol=1e-6)
+        R = np.ascontiguousarray(T[:3, :3]); e = np.zeros(3, np.float32)
+        lib().orc_pclndt_euler(R.ctypes.data, e.ctypes.data)
+        # Eigen returns the representation with the first angle in [0, pi]: the same rotation, maybe other angles
+        assert 0.0 <= e[0] <= np.pi + 1e-6
+        assert np.allclose(Rotation.from_euler("XYZ", e.astype(np.float64)).as_matrix(), R, atol=2e-6)
+        A = rng.normal(size=(6, 6)); A = A @ A.T + 0.1 * np.eye(6); b = rng.normal(size=6); x = np.zeros(6)
+        lib().orc_pclndt_svd_solve(A.ctypes.data, b.ctypes.data, x.ctypes.data)
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9)
+
+
+def test_pclndt_oracle_align(synth):
+    from oracle import Oracle
+    from oracle.loader import result_T
+    p = synth.make_pair(0, 10000, 100000, density=60.0)
+    o = Oracle("NDT_OMP", "LM", voxel_resolution=1.0, num_neighbors=7, translation_eps=0.1, max_iterations=35)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    r = o.align(p.guess)
+    assert r.converged and r.iterations >= 1
+    e0, _ = pose_error(p.guess, p.T_gt)
+    e1, _ = pose_error(result_T(r), p.T_gt)
+    assert e1 < e0          # epsilon 0.1 m: the reference stops as soon as a step is shorter than 10 cm
