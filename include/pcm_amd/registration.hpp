@@ -125,6 +125,7 @@ protected:
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) final_hessian_(i, j) = r.H[i * 6 + j];
     nr_iterations_ = r.iterations;
     converged_ = r.converged != 0;
+    last_cost_ = r.cost;
     pcl::transformPointCloud(*input_, output, final_transformation_);                    // :78
   }
 
@@ -140,6 +141,7 @@ protected:
   pcm_ctx* ctx_ = nullptr;
   pcm_config cfg_;
   Eigen::Matrix<double, 6, 6> final_hessian_;
+  double last_cost_ = 0.0;   // cost (LSQ models) / score (pclomp NDT) of the last evaluation
 };
 
 // point-to-plane scan-to-submap ICP with jueying_lio's matcher semantics
@@ -201,6 +203,35 @@ public:
   }
   void setDistanceMode(NDTDistanceMode m) { this->cfg_.model = m == NDTDistanceMode::P2D ? PCM_MODEL_NDT_P2D : PCM_MODEL_NDT_D2D; }
   void setNeighborSearchMethod(NeighborSearchMethod m, double /*radius*/ = -1.0) { this->cfg_.num_neighbors = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1); }
+};
+
+// pclomp::NormalDistributionsTransform (ndt_omp/include/pclomp/ndt_omp.h:77-310): the operator jueying_slam's
+// localization constructs (jueying_slam/src/localization.cpp:162-189).  Defaults of that class (ndt_omp_impl.hpp:48,60-63).
+enum NeighborSearchMethodOmp { KDTREE, DIRECT26, DIRECT7, DIRECT1 };   // ndt_omp.h:60
+template <typename PointSource, typename PointTarget>
+class PclNdtRegistration : public LsqRegistration<PointSource, PointTarget> {
+public:
+  explicit PclNdtRegistration(int device = 0) : LsqRegistration<PointSource, PointTarget>(PCM_MODEL_NDT_OMP, device) {
+    this->reg_name_ = "pcm_amd::PclNdtRegistration";
+    this->cfg_.voxel_resolution = 1.0f;
+    this->cfg_.num_neighbors = 7;
+    this->max_iterations_ = 35;
+    this->transformation_epsilon_ = 0.1;
+  }
+  void setStepSize(double s) { this->cfg_.ndt_step_size = static_cast<float>(s); }               // ndt_omp.h:166
+  void setOulierRatio(double r) { this->cfg_.ndt_outlier_ratio = static_cast<float>(r); }        // ndt_omp.h:184 (sic)
+  void setNeighborhoodSearchMethod(NeighborSearchMethodOmp m) {                                  // ndt_omp.h:198
+    if (m == KDTREE) throw std::runtime_error("pcm_amd::PclNdtRegistration: KDTREE neighbourhood search is not built");
+    this->cfg_.num_neighbors = m == DIRECT26 ? 27 : (m == DIRECT7 ? 7 : 1);
+  }
+  double getTransformationProbability() const { return trans_probability_; }                     // ndt_omp.h:207
+protected:
+  void computeTransformation(typename LsqRegistration<PointSource, PointTarget>::PointCloudSource& output,
+                             const typename LsqRegistration<PointSource, PointTarget>::Matrix4& guess) override {
+    LsqRegistration<PointSource, PointTarget>::computeTransformation(output, guess);
+    trans_probability_ = this->last_cost_ / static_cast<double>(this->input_->points.size());   // ndt_omp_impl.hpp:145
+  }
+  double trans_probability_ = 0.0;
 };
 
 }  // namespace pcm_amd
