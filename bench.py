@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="independent batches in flight per GPU (each on its own stream / host thread), so the few slow-converging "
                          "pairs of one batch run under the bulk of the next")
+    ap.add_argument("--window", type=int, default=0, help="pairs of a sub-batch iterating at a time (0 = all): finished pairs hand their slot to queued ones")
     ap.add_argument("--scan-points", type=int, default=100000)
     ap.add_argument("--map-points", type=int, default=1000000)
     ap.add_argument("--optimizer", default="GN", choices=["GN", "LM"])
@@ -127,7 +128,7 @@ def main():
         d_map = torch.from_numpy(submap).to(dev)
         d_inputs.append((d_scan, d_map))
         r = pcm.P2PlaneRegistration(local_rank, optimizer=args.optimizer, voxel_resolution=cfg["voxel_resolution"],
-                                    num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source)
+                                    num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source, batch_window=args.window)
         r.set_input_target(d_map)
         r.set_input_source(d_scan)
         regs.append(r)

@@ -95,7 +95,8 @@ typedef struct pcm_config {
   int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
   float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
-  int32_t reserved[3];
+  int32_t batch_window;          /* pcm_align_batch: pairs iterating at a time; finished pairs hand their slot to queued ones (0 = all at once; speed only) */
+  int32_t reserved[2];
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */

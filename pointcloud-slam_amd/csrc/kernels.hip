@@ -191,7 +191,8 @@ __device__ inline void unpack_sums(const double* s, double* H, double* b, double
 }
 
 __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restrict__ descs, PairState* __restrict__ states, KernelParams kp, LsqParams lp, int trial_round,
-                                                       int write_flags, unsigned char* __restrict__ flags_row, double* __restrict__ sums_out) {
+                                                       int write_flags, unsigned char* __restrict__ flags_row, double* __restrict__ sums_out, unsigned int* __restrict__ queue,
+                                                       int npairs) {
   const int pair = blockIdx.x;
   const int mode = states[pair].mode;
   if (mode == (trial_round ? MODE_TRIAL : MODE_LINEARIZE)) {
@@ -230,6 +231,11 @@ __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restric
         } else {
           after_trial(st, lp, s_tot[27]);
         }
+        // batch window: a pair that just finished hands its slot to the next queued pair (first active in the next round)
+        if (st.mode == MODE_DONE && queue) {
+          const unsigned int next = atomicAdd(queue, 1u);
+          if (next < (unsigned int)npairs) states[next].mode = MODE_LINEARIZE;
+        }
       } else {
         for (int k = 0; k < kNumSums; k++) sums_out[pair * kPartialStride + k] = s_tot[k];
       }
@@ -241,8 +247,8 @@ __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restric
 }
 
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
-                         bool write_flags, unsigned char* d_flags_row, double* d_sums) {
-  k_finish_round<<<npairs, 1024, 0, stream>>>(d_descs, d_states, kp, lp, trial_round ? 1 : 0, write_flags ? 1 : 0, d_flags_row, d_sums);
+                         bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue) {
+  k_finish_round<<<npairs, 1024, 0, stream>>>(d_descs, d_states, kp, lp, trial_round ? 1 : 0, write_flags ? 1 : 0, d_flags_row, d_sums, d_queue, npairs);
 }
 
 // ---------------------------------------------------------------------------
@@ -768,17 +774,19 @@ void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* 
   k_trial<<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
 }
 
-__global__ void k_init_states(PairState* __restrict__ states, const float* __restrict__ guesses, int npairs, int max_iterations) {
+__global__ void k_init_states(PairState* __restrict__ states, const float* __restrict__ guesses, int npairs, int max_iterations, int window, unsigned int* __restrict__ queue) {
   const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair == 0 && queue) *queue = (unsigned int)window;   // next pair to activate
   if (pair >= npairs) return;
   PairState s;
   init_state(s, guesses + pair * 16);
   if (max_iterations <= 0) s.mode = MODE_DONE;
+  else if (pair >= window) s.mode = MODE_WAIT;
   states[pair] = s;
 }
 
-void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations) {
-  k_init_states<<<(npairs + 63) / 64, 64, 0, stream>>>(d_states, d_guesses, npairs, max_iterations);
+void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations, int window, unsigned int* d_queue) {
+  k_init_states<<<(npairs + 63) / 64, 64, 0, stream>>>(d_states, d_guesses, npairs, max_iterations, window, d_queue);
 }
 
 __global__ void k_pack_results(const PairState* __restrict__ states, pcm_result* __restrict__ out, int npairs) {

@@ -16,7 +16,7 @@ namespace pcm {
 
 #define PCM_HD __host__ __device__ inline
 
-enum PairMode : int32_t { MODE_LINEARIZE = 0, MODE_TRIAL = 1, MODE_DONE = 2 };
+enum PairMode : int32_t { MODE_LINEARIZE = 0, MODE_TRIAL = 1, MODE_DONE = 2, MODE_WAIT = 3 };   // WAIT: queued behind the batch window
 
 // Per-pair optimiser state, resident in device memory for the whole align().
 struct PairState {

@@ -43,6 +43,7 @@ struct Workspace {
   unsigned char* h_flags = nullptr;  // mapped pinned host memory: [round][pair] status bytes written by k_finish_round
   size_t cap_flags = 0;
   unsigned long long* d_stats = nullptr;
+  unsigned int* d_queue = nullptr;   // batch window: index of the next queued pair
   SortJob* d_jobs = nullptr;
   SortScratch sort;
   int cap_pairs = 0;
@@ -87,6 +88,7 @@ int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, i
     w.cap_flags = bytes;
   }
   if (!w.d_stats) HIPCK(c, hipMalloc(&w.d_stats, sizeof(unsigned long long) * 16));
+  if (!w.d_queue) HIPCK(c, hipMalloc(&w.d_queue, sizeof(unsigned int)));
   while ((int)w.ev_round.size() < 2) {
     hipEvent_t e;
     HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -100,7 +102,7 @@ void free_ws(pcm_ctx* c) {
   Workspace* w = static_cast<Workspace*>(c->ws);
   if (!w) return;
   hipFree(w->d_descs); hipFree(w->d_states); hipFree(w->d_guesses); hipFree(w->d_results); hipFree(w->d_partials); hipFree(w->d_sums);
-  hipFree(w->d_stats); hipFree(w->d_jobs); hipFree(w->sort.keys); hipFree(w->sort.vals); hipFree(w->sort.tmp);
+  hipFree(w->d_stats); hipFree(w->d_queue); hipFree(w->d_jobs); hipFree(w->sort.keys); hipFree(w->sort.vals); hipFree(w->sort.tmp);
   if (w->h_flags) hipHostFree(w->h_flags);
   for (hipEvent_t e : w->ev_round) hipEventDestroy(e);
   for (hipEvent_t e : w->ev_prof) hipEventDestroy(e);
@@ -430,7 +432,11 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   const LsqParams lp = lsq_params(g);
   const KernelParams kp = kernel_params(g, geom);
   // worst case: every outer iteration = 1 linearize + lm_max_iterations trials
-  const int max_rounds = std::max(1, g.max_iterations) * (g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT ? 1 + std::max(1, g.lm_max_iterations) : 1) + 1;
+  // batch window: at most `window` pairs iterate at a time, a finished pair's slot goes to the next queued one on the
+  // device (k_finish_round) -- the late rounds of a slow pair then overlap the early rounds of its successors
+  const int window = (g.batch_window > 0 && g.max_iterations > 0) ? std::min(n, g.batch_window) : n;
+  const int per_pair_rounds = std::max(1, g.max_iterations) * (g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT ? 1 + std::max(1, g.lm_max_iterations) : 1);
+  const int max_rounds = per_pair_rounds * (n - window + 1) + 1;
   const size_t per_pair_partials = (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride;
   Workspace* w = nullptr;
   int rc = ensure_ws(c0, &w, n, per_pair_partials * n, max_rounds);
@@ -460,7 +466,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   for (int i = 0; i < n; i++) fill_desc(ctxs[i], &descs[i], w->d_partials + per_pair_partials * i);
   HIPCK(c0, hipMemcpyAsync(w->d_descs, descs.data(), sizeof(PairDesc) * n, hipMemcpyHostToDevice, st));
   std::memset(w->h_flags, 0, (size_t)max_rounds * n);
-  launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations);
+  launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations, window, w->d_queue);
   const bool stats_on = (c0->profiling & 1) != 0;      // HIP events around the residual launches
   const bool timing_on = (c0->profiling & 4) != 0;     // diagnostic: in-kernel phase stamps (stats.phase_cycles)
   const bool counters_on = (c0->profiling & 2) != 0 || timing_on;   // kNN candidate / probe counters (slower kernel variant)
@@ -481,12 +487,12 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_VGICP, false);
     else launch_linearize(st, w->d_descs, w->d_states, kp, n, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
-    launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums);
+    launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, w->d_queue);
     if (is_lm) {
       if (ndt) launch_ndt(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_NDT_D2D, true);
       else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_VGICP, true);
       else launch_trial(st, w->d_descs, w->d_states, kp, n);
-      launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, true, true, w->d_flags + (size_t)r * n, w->d_sums);
+      launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, true, true, w->d_flags + (size_t)r * n, w->d_sums, w->d_queue);
     }
     if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st)); prof_used += 3; }
     rounds_done = r + 1;

@@ -91,7 +91,7 @@ void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState
 void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out);
 void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs);
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
-                         bool write_flags, unsigned char* d_flags_row, double* d_sums);
+                         bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue = nullptr);
 void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool d2d, bool trial);
 void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
@@ -101,7 +101,7 @@ int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d
 int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err);
 int pclndt_workgroups(uint32_t n, uint32_t* per_out);
 void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out);
-void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations);
+void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations, int window, unsigned int* d_queue);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
 
 }  // namespace pcm

@@ -261,3 +261,19 @@ def test_full_size_properties(pcm, synth):
     g.set_input_source(p.scan)
     rb = pcm.align_batch([g], p.guess[None])[0]
     assert np.array_equal(rb.T64, r.T64)
+
+
+@pytest.mark.parametrize("optimizer", ["GN", "LM"])
+def test_batch_window_equals_singles(pcm, synth, optimizer):
+    """pcm_config.batch_window (speed only): queued pairs take over the slots of finished ones on the device;
+    every pair's result is the one it gets alone."""
+    pairs = [synth.make_pair(60 + i, 2000 + 300 * i, 20000 + 2000 * i) for i in range(7)]
+    for window in (1, 3):
+        regs = []
+        for p in pairs:
+            g = pcm.P2PlaneRegistration(0, optimizer=optimizer, batch_window=window)
+            g.set_input_target(p.submap); g.set_input_source(p.scan); regs.append(g)
+        singles = [g.align(p.guess) for g, p in zip(regs, pairs)]
+        batch = pcm.align_batch(regs, np.stack([p.guess for p in pairs]))
+        for s, b in zip(singles, batch):
+            assert np.array_equal(s.T64, b.T64) and s.iterations == b.iterations and s.converged == b.converged
