@@ -475,7 +475,7 @@ __device__ inline void load6(const double* p, double (&C)[9]) {
 // ---------------------------------------------------------------------------
 template <bool VG, bool TRIAL>
 __global__ void __launch_bounds__(256) k_gicp(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
-  const int pair = blockIdx.y;
+  const int pair = PCM_PAIR_OF(kp, blockIdx.y);
   const int mode = states[pair].mode;
   if (mode != (TRIAL ? MODE_TRIAL : MODE_LINEARIZE)) return;
   const PairDesc d = descs[pair];

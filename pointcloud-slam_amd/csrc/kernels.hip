@@ -193,7 +193,7 @@ __device__ inline void unpack_sums(const double* s, double* H, double* b, double
 __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restrict__ descs, PairState* __restrict__ states, KernelParams kp, LsqParams lp, int trial_round,
                                                        int write_flags, unsigned char* __restrict__ flags_row, double* __restrict__ sums_out, unsigned int* __restrict__ queue,
                                                        int npairs) {
-  const int pair = blockIdx.x;
+  const int pair = PCM_PAIR_OF(kp, blockIdx.x);
   const int mode = states[pair].mode;
   if (mode == (trial_round ? MODE_TRIAL : MODE_LINEARIZE)) {
     __shared__ double s_grp[32 * kPartialStride];
@@ -247,8 +247,8 @@ __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restric
 }
 
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
-                         bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue) {
-  k_finish_round<<<npairs, 1024, 0, stream>>>(d_descs, d_states, kp, lp, trial_round ? 1 : 0, write_flags ? 1 : 0, d_flags_row, d_sums, d_queue, npairs);
+                         bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue, int total_pairs) {
+  k_finish_round<<<npairs, 1024, 0, stream>>>(d_descs, d_states, kp, lp, trial_round ? 1 : 0, write_flags ? 1 : 0, d_flags_row, d_sums, d_queue, total_pairs > 0 ? total_pairs : npairs);
 }
 
 // ---------------------------------------------------------------------------
@@ -271,7 +271,7 @@ constexpr uint16_t kNoCell = 0xffffu;
 template <bool STATS, bool TIMING, bool WRITE_PLANES, bool LIO>
 __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
                                                       unsigned long long* __restrict__ stats) {
-  const int pair = blockIdx.y;
+  const int pair = PCM_PAIR_OF(kp, blockIdx.y);
   if (states[pair].mode != MODE_LINEARIZE) return;
   const PairDesc d = descs[pair];
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -735,7 +735,7 @@ void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks
 // grid = (blocks_per_pair, npairs), block = 256
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_trial(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
-  const int pair = blockIdx.y;
+  const int pair = PCM_PAIR_OF(kp, blockIdx.y);
   if (states[pair].mode != MODE_TRIAL) return;
   const PairDesc d = descs[pair];
   const uint32_t begin = blockIdx.x * (uint32_t)kp.points_per_block;

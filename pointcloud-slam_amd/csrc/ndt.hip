@@ -86,7 +86,7 @@ __device__ inline double wave_sum_d(double v) {
 // ---------------------------------------------------------------------------
 template <bool D2D, bool TRIAL>
 __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
-  const int pair = blockIdx.y;
+  const int pair = PCM_PAIR_OF(kp, blockIdx.y);
   const int mode = states[pair].mode;
   if (mode != (TRIAL ? MODE_TRIAL : MODE_LINEARIZE)) return;
   const PairDesc d = descs[pair];

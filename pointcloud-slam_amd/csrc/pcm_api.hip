@@ -476,31 +476,48 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
 
   int rounds_done = 0;
   size_t prof_used = 0;
+  // Only the pairs the host still believes active are launched (the list rides in the kernel arguments, batches of
+  // <= 64 pairs): an early-exit workgroup is not free, and the late rounds of a batch have one or two live pairs.
+  // The list lags one round (the status bytes are read one round behind); a stale entry exits at once.
+  const bool use_list = n <= 64 && window == n;
+  std::vector<uint8_t> act((size_t)n);
+  for (int i = 0; i < n; i++) act[(size_t)i] = (uint8_t)i;
+  std::vector<uint8_t> prev_list;
+  KernelParams kpr = kp;
   for (int r = 0; r < max_rounds; r++) {
+    const int nl = use_list ? (int)act.size() : n;
+    if (use_list) {
+      kpr.use_list = 1;
+      std::memcpy(kpr.active, act.data(), act.size());
+    }
     if (stats_on) {
       while (w->ev_prof.size() < prof_used + 3) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
       HIPCK(c0, hipEventRecord(w->ev_prof[prof_used], st));
     }
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
-    if (ndt) launch_ndt(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_NDT_D2D, false);
-    else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_VGICP, false);
-    else launch_linearize(st, w->d_descs, w->d_states, kp, n, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
+    if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_NDT_D2D, false);
+    else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
+    else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
-    launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, w->d_queue);
+    launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
     if (is_lm) {
-      if (ndt) launch_ndt(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_NDT_D2D, true);
-      else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kp, n, g.model == PCM_MODEL_VGICP, true);
-      else launch_trial(st, w->d_descs, w->d_states, kp, n);
-      launch_finish_round(st, w->d_descs, w->d_states, kp, lp, n, true, true, w->d_flags + (size_t)r * n, w->d_sums, w->d_queue);
+      if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_NDT_D2D, true);
+      else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, true);
+      else launch_trial(st, w->d_descs, w->d_states, kpr, nl);
+      launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, true, true, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
     }
     if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st)); prof_used += 3; }
     rounds_done = r + 1;
+    std::vector<uint8_t> this_list = act;   // pairs launched in round r
     if (r >= 1) {  // look one round behind so the GPU always has the next round queued
       volatile unsigned char* row = w->h_flags + (size_t)(r - 1) * n;
       bool any_active = false;
       const auto t_start = std::chrono::steady_clock::now();
-      for (int i = 0; i < n; i++) {
+      std::vector<uint8_t> alive;
+      const int np = use_list ? (int)prev_list.size() : n;
+      for (int k = 0; k < np; k++) {
+        const int i = use_list ? (int)prev_list[(size_t)k] : k;
         unsigned spins = 0;
         while (row[i] == 0) {   // the round's status byte of pair i has not landed yet
           if ((++spins & 0xfff) == 0) {
@@ -509,9 +526,12 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
           }
         }
         any_active |= row[i] == 1;
+        if (row[i] == 1 && use_list) alive.push_back((uint8_t)i);
       }
       if (!any_active) break;
+      if (use_list) act.swap(alive);
     }
+    prev_list.swap(this_list);
   }
   HIPCK(c0, hipGetLastError());
   pcm_result* d_res = device_out ? static_cast<pcm_result*>(device_out) : w->d_results;

@@ -192,6 +192,9 @@ struct PairDesc {
   unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)
 };
 
+// pair handled by grid entry b
+#define PCM_PAIR_OF(kp, b) ((kp).use_list ? (int)(kp).active[(b)] : (int)(b))
+
 constexpr int kNumSums = 29;        // 21 (H upper) + 6 (b) + cost + inlier count
 constexpr int kPartialStride = 32;  // doubles per block partial (padded)
 constexpr int kLioSums = 92;        // 78 (HTH upper) + 12 (H^T h) + sum h^2 + count
@@ -212,6 +215,8 @@ struct KernelParams {
   int32_t lio_extrinsic;      // LIO: extrinsic_est_en (columns 6..11 of h_x)
   int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)
   int32_t coord_mode;         // CoordMode of the target map (GICP / VGICP kernels)
+  int32_t use_list;           // 1: the grid's pair axis indexes `active` (only pairs the host still believes active are launched)
+  uint8_t active[64];         // pair index of each grid entry (batches of <= 64 pairs)
   double max_corr_sq;         // GICP: corr_dist_threshold_^2 (double, as pcl::Registration holds it)
 };
 

@@ -91,7 +91,7 @@ void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState
 void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out);
 void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs);
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
-                         bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue = nullptr);
+                         bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue = nullptr, int total_pairs = 0);
 void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool d2d, bool trial);
 void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
