@@ -11,7 +11,8 @@ sel = rows[start:end]
 t0 = int(sel[0]['Start_Timestamp']); prev = None; tot = {}
 for r in sel:
     s = int(r['Start_Timestamp']); e = int(r['End_Timestamp'])
-    n = r['Kernel_Name'].split('(')[0][-26:]
+    full = r['Kernel_Name']
+    n = 'k_linearize' if 'k_linearize' in full else full.split('(')[0][-26:]
     tot[n] = tot.get(n, 0) + (e - s) / 1e3
     if any(k in n for k in ('k_linearize', 'k_finish', 'k_trial')):
         print("%8.1f dur %6.1f gap %5.1f %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0, n))
