@@ -83,13 +83,24 @@ __device__ inline void transform(const PoseF& P, const float4& p, float (&q)[3])
 struct Best {
   float d[K];
   uint32_t i[K];
-  int m;
+  float thr;   // min(d[K - 1], max_range^2): a candidate changes the list iff its distance is below this
+  int m;       // candidates within max_range, at most K (= finite entries of d; set by best_finish)
 };
 
-__device__ inline void best_init(Best& b) {
+__device__ inline void best_init(Best& b, float max_r2f) {
 #pragma unroll
   for (int j = 0; j < K; j++) { b.d[j] = __builtin_inff(); b.i[j] = 0xffffffffu; }
+  b.thr = max_r2f;
   b.m = 0;
+}
+
+// every in-range candidate enters the list while it has a free (infinite) slot, so the reference's
+// count min(K, #in range) is the number of finite entries
+__device__ inline void best_finish(Best& b) {
+  int m = 0;
+#pragma unroll
+  for (int j = 0; j < K; j++) m += b.d[j] < __builtin_inff() ? 1 : 0;
+  b.m = m;
 }
 
 // Offer one map point.  `max_r2f` is the smallest float >= max_range^2, so
@@ -100,9 +111,8 @@ __device__ inline void best_init(Best& b) {
 __device__ inline void best_offer(Best& b, const float4& mp, const float (&q)[3], uint32_t id, float max_r2f) {
   const float dx = mp.x - q[0], dy = mp.y - q[1], dz = mp.z - q[2];
   const float d2 = dx * dx + dy * dy + dz * dz;  // distance2()  ivox3d_node.hpp:13-16
-  if (d2 < max_r2f) {
-    b.m = b.m < K ? b.m + 1 : K;
-    if (d2 < b.d[4]) {
+  if (d2 < b.thr) {   // in range (d2 < max_r2f) and ahead of the current K-th (strict: an equal distance stays behind)
+    {
       const bool c0 = d2 < b.d[0], c1 = d2 < b.d[1], c2 = d2 < b.d[2], c3 = d2 < b.d[3];
       b.i[4] = c3 ? b.i[3] : id;
       b.d[4] = fmaxf(d2, b.d[3]);
@@ -114,6 +124,7 @@ __device__ inline void best_offer(Best& b, const float4& mp, const float (&q)[3]
       b.d[1] = __builtin_amdgcn_fmed3f(d2, b.d[0], b.d[1]);
       b.i[0] = c0 ? id : b.i[0];
       b.d[0] = fminf(d2, b.d[0]);
+      b.thr = fminf(b.d[4], max_r2f);
     }
   }
 }
@@ -376,7 +387,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
     PCM_STAMP(0)   // load + transform + tile box
 
     Best best;
-    best_init(best);
+    best_init(best, kp.max_range_sq);
 
     if (use_lds) {
       const int ox0 = s_box[0], oy0 = s_box[1], oz0 = s_box[2];
@@ -490,6 +501,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
       }
     }
     if (!use_lds && search) knn_global<STATS>(tg, q, cx, cy, cz, kp.num_neighbors, kp.max_range_sq, best, n_cand, n_probe);
+    best_finish(best);
     if constexpr (LIO) {   // nearest_points_[i] for MapIncremental: indices into the map's point array, nearest first
       if (live) {
 #pragma unroll
