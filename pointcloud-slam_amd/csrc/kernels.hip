@@ -115,7 +115,9 @@ __device__ inline void best_offer(Best& b, const float4& mp, const float (&q)[3]
     {
       const bool c0 = d2 < b.d[0], c1 = d2 < b.d[1], c2 = d2 < b.d[2], c3 = d2 < b.d[3];
       b.i[4] = c3 ? b.i[3] : id;
-      b.d[4] = fmaxf(d2, b.d[3]);
+      // distances are non-negative and never NaN here: unsigned integer min / max of the bit patterns order them
+      // exactly and skip the NaN canonicalisation fminf / fmaxf carry
+      b.d[4] = __uint_as_float(max(__float_as_uint(d2), __float_as_uint(b.d[3])));
       b.i[3] = c2 ? b.i[2] : (c3 ? id : b.i[3]);
       b.d[3] = __builtin_amdgcn_fmed3f(d2, b.d[2], b.d[3]);
       b.i[2] = c1 ? b.i[1] : (c2 ? id : b.i[2]);
@@ -123,8 +125,8 @@ __device__ inline void best_offer(Best& b, const float4& mp, const float (&q)[3]
       b.i[1] = c0 ? b.i[0] : (c1 ? id : b.i[1]);
       b.d[1] = __builtin_amdgcn_fmed3f(d2, b.d[0], b.d[1]);
       b.i[0] = c0 ? id : b.i[0];
-      b.d[0] = fminf(d2, b.d[0]);
-      b.thr = fminf(b.d[4], max_r2f);
+      b.d[0] = __uint_as_float(min(__float_as_uint(d2), __float_as_uint(b.d[0])));
+      b.thr = __uint_as_float(min(__float_as_uint(b.d[4]), __float_as_uint(max_r2f)));
     }
   }
 }
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
       for (int j = 0; j < kCapCells / 256; j++) s_cell[threadIdx.x + 256 * j] = kNoCell;
       __syncthreads();
       const uint32_t total = s_boff[kCapBricks];
-      use_lds = total <= (uint32_t)kCapPts;   // still uniform
+      use_lds = total < (uint32_t)kCapPts;   // still uniform; one slot is kept for the end-of-run sentinel
       PCM_STAMP(1)   // brick probes
       if (use_lds) {
         // ---- stage the bricks' map points through LDS: flat, coalesced, all loads in flight --------
@@ -448,6 +450,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
           const uint32_t k = threadIdx.x + 256u * r;
           if (k < total) s_pts[k] = v[r];
         }
+        if (threadIdx.x == 0) s_pts[total] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));   // end-of-run sentinel
         __syncthreads();
         PCM_STAMP(2)   // stage map points
         // ---- every voxel head among the staged points registers itself in the cell grid ------------
@@ -480,23 +483,27 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
             kh[g] = kNoCell;
             if (g < kp.num_neighbors) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
           }
-          const uint32_t last = total - 1;
+          // a voxel's points are one run of s_pts; s_pts[total] is a sentinel whose tag matches no voxel, so the
+          // run ends on a tag change alone.  The list carries byte offsets (k * 16) until the search is over.
+          const char* pbase = reinterpret_cast<const char*>(s_pts);
   #pragma unroll
           for (int g = 0; g < 27; g++) {
             if (kh[g] != kNoCell) {
-              uint32_t k = kh[g];
-              float4 mp = s_pts[k];
+              uint32_t off = (uint32_t)kh[g] << 4;
+              float4 mp = *reinterpret_cast<const float4*>(pbase + off);
               const int tag = __float_as_int(mp.w);
               for (;;) {
-                const float4 nx = s_pts[k < last ? k + 1 : last];
+                const float4 nx = *reinterpret_cast<const float4*>(pbase + off + 16);
                 if (STATS) n_cand++;
-                best_offer(best, mp, q, k, kp.max_range_sq);
-                if (k >= last || __float_as_int(nx.w) != tag) break;
+                best_offer(best, mp, q, off, kp.max_range_sq);
+                if (__float_as_int(nx.w) != tag) break;
                 mp = nx;
-                k++;
+                off += 16;
               }
             }
           }
+  #pragma unroll
+          for (int j = 0; j < K; j++) best.i[j] >>= 4;
         }
       }
     }
