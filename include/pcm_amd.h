@@ -96,7 +96,8 @@ typedef struct pcm_config {
   float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
   int32_t batch_window;          /* pcm_align_batch: pairs iterating at a time; finished pairs hand their slot to queued ones (0 = all at once; speed only) */
-  int32_t reserved[2];
+  int32_t voxel_mode;            /* VGICP VoxelAccumulationMode (gicp_settings.hpp:10): 0 ADDITIVE (default), 1 ADDITIVE_WEIGHTED, 2 MULTIPLICATIVE */
+  int32_t reserved[1];
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */

@@ -23,7 +23,7 @@ class OracleConfig(C.Structure):
                 ("min_knn", C.c_int), ("max_range", C.c_double), ("plane_threshold", C.c_double),
                 ("max_corr_dist", C.c_double), ("k_correspondences", C.c_int),
                 ("regularization", C.c_int), ("num_threads", C.c_int), ("map_capacity", C.c_long),
-                ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double)]
+                ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double), ("voxel_mode", C.c_int)]
 
 
 class LioState(C.Structure):

@@ -203,19 +203,35 @@ static void vgicp_build_voxelmap(oracle *o, orc_gicp_state *s) {
   const double res = o->cfg.voxel_resolution;
   orc_vhash_init(&s->vh, o->tgt.n);
   s->vox = (orc_vgvox *)calloc((size_t)o->tgt.n + 1, sizeof(orc_vgvox));
+  const int mult = o->cfg.voxel_mode == 2;   /* MultiplicativeGaussianVoxel  fast_vgicp_voxel.hpp:79-102 */
   for (long i = 0; i < o->tgt.n; i++) {
     const float *p = o->tgt.xyz + 3 * i;
     int c[3];
     for (int a = 0; a < 3; a++) c[a] = (int)floor((double)p[a] / res - 0.5);       /* voxel_coord on Vector4d  :158-160 */
     orc_vgvox *v = &s->vox[orc_vhash_insert(&s->vh, c[0], c[1], c[2])];
     v->n++;
-    for (int a = 0; a < 3; a++) v->mean[a] += (double)p[a];
-    for (int a = 0; a < 9; a++) v->cov[a] += s->tgt_cov[9 * i + a];
+    if (mult) {   /* cov_inv = cov_ with (3,3) = 1, inverted (block inverse = the 3x3 inverse); cov += cov_inv; mean += cov_inv * mean_ */
+      double Ci[9];
+      orc_inv3d(s->tgt_cov + 9 * i, Ci);
+      for (int a = 0; a < 9; a++) v->cov[a] += Ci[a];
+      for (int a = 0; a < 3; a++) v->mean[a] += (Ci[a * 3 + 0] * (double)p[0] + Ci[a * 3 + 1] * (double)p[1]) + Ci[a * 3 + 2] * (double)p[2];
+    } else {      /* AdditiveGaussianVoxel (ADDITIVE and ADDITIVE_WEIGHTED)  :104-122 */
+      for (int a = 0; a < 3; a++) v->mean[a] += (double)p[a];
+      for (int a = 0; a < 9; a++) v->cov[a] += s->tgt_cov[9 * i + a];
+    }
   }
   s->nvox = s->vh.count;
-  for (long j = 0; j < s->nvox; j++) {                                               /* finalize()  :116-121 */
-    for (int a = 0; a < 3; a++) s->vox[j].mean[a] /= s->vox[j].n;
-    for (int a = 0; a < 9; a++) s->vox[j].cov[a] /= s->vox[j].n;
+  for (long j = 0; j < s->nvox; j++) {                                               /* finalize() */
+    if (mult) {   /* cov = cov^-1 ; mean = cov * mean  :96-101 */
+      double C[9], m[3];
+      orc_inv3d(s->vox[j].cov, C);
+      for (int a = 0; a < 3; a++) m[a] = (C[a * 3 + 0] * s->vox[j].mean[0] + C[a * 3 + 1] * s->vox[j].mean[1]) + C[a * 3 + 2] * s->vox[j].mean[2];
+      memcpy(s->vox[j].cov, C, sizeof(C));
+      memcpy(s->vox[j].mean, m, sizeof(m));
+    } else {
+      for (int a = 0; a < 3; a++) s->vox[j].mean[a] /= s->vox[j].n;
+      for (int a = 0; a < 9; a++) s->vox[j].cov[a] /= s->vox[j].n;
+    }
   }
   s->vmap_valid = 1;
 }

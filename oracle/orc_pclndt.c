@@ -560,7 +560,6 @@ done:
 /* ---- unit hooks ------------------------------------------------------------------------------- */
 double orc_pclndt_derivatives(void *h, const double p[6], int compute_hessian, double g[6], double H[36]) {
   oracle *o = (oracle *)h;
-  orc_pclndt_state *s = ps(o);
   build_leaves(o);
   gauss_params(o);
   float T[16];

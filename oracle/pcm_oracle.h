@@ -47,6 +47,7 @@ typedef struct orc_config {
   long map_capacity;          /* ivox3d.h:57 capacity_ 1000000 (0 = unlimited) */
   double ndt_step_size;       /* ndt_omp_impl.hpp:48 step_size_ 0.1 (More-Thuente maximum step) */
   double ndt_outlier_ratio;   /* ndt_omp_impl.hpp:48 outlier_ratio_ 0.55 */
+  int voxel_mode;             /* VGICP VoxelAccumulationMode: 0 ADDITIVE (fast_vgicp_impl.hpp:25), 1 ADDITIVE_WEIGHTED, 2 MULTIPLICATIVE */
 } orc_config;
 
 typedef struct orc_result {

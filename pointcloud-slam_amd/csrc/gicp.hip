@@ -411,28 +411,46 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
 }
 
 // voxel distributions of the VGICP map: a voxel's points are one run in input order
+// mode 0 / 1: AdditiveGaussianVoxel (fast_vgicp_voxel.hpp:104-122); mode 2: MultiplicativeGaussianVoxel (:79-102)
 __global__ void __launch_bounds__(128) k_vgicp_voxels(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, const double* __restrict__ covs,
-                                                      uint32_t nvox, VgVoxel* __restrict__ out) {
+                                                      uint32_t nvox, int mode, VgVoxel* __restrict__ out) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
   const uint32_t p0 = vox_start[v], p1 = vox_start[v + 1];
-  VgVoxel g;
-#pragma unroll
-  for (int a = 0; a < 3; a++) g.mean[a] = 0.0;
-#pragma unroll
-  for (int a = 0; a < 6; a++) g.cov[a] = 0.0;
-  for (uint32_t p = p0; p < p1; p++) {   // append()  fast_vgicp_voxel.hpp:111-115
+  double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (uint32_t p = p0; p < p1; p++) {   // append()
     const float4 c = pts[p];
-    g.mean[0] += (double)c.x; g.mean[1] += (double)c.y; g.mean[2] += (double)c.z;
+    const double x[3] = {(double)c.x, (double)c.y, (double)c.z};
+    const double* s6 = covs + (size_t)p * 6;
+    const double C[9] = {s6[0], s6[1], s6[2], s6[1], s6[3], s6[4], s6[2], s6[4], s6[5]};
+    if (mode == 2) {
+      double Ci[9];
+      inv3<double>(C, Ci);
 #pragma unroll
-    for (int a = 0; a < 6; a++) g.cov[a] += covs[(size_t)p * 6 + a];
+      for (int a = 0; a < 9; a++) cov[a] += Ci[a];
+#pragma unroll
+      for (int a = 0; a < 3; a++) mean[a] += (Ci[a * 3 + 0] * x[0] + Ci[a * 3 + 1] * x[1]) + Ci[a * 3 + 2] * x[2];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) mean[a] += x[a];
+#pragma unroll
+      for (int a = 0; a < 9; a++) cov[a] += C[a];
+    }
   }
+  VgVoxel g;
   g.n = (int32_t)(p1 - p0);
   g.pad = 0;
+  if (mode == 2) {   // finalize(): cov = cov^-1, mean = cov * mean
+    double C[9];
+    inv3<double>(cov, C);
 #pragma unroll
-  for (int a = 0; a < 3; a++) g.mean[a] /= g.n;   // finalize()  :117-120
+    for (int a = 0; a < 3; a++) g.mean[a] = (C[a * 3 + 0] * mean[0] + C[a * 3 + 1] * mean[1]) + C[a * 3 + 2] * mean[2];
+    g.cov[0] = C[0]; g.cov[1] = C[1]; g.cov[2] = C[2]; g.cov[3] = C[4]; g.cov[4] = C[5]; g.cov[5] = C[8];
+  } else {
 #pragma unroll
-  for (int a = 0; a < 6; a++) g.cov[a] /= g.n;
+    for (int a = 0; a < 3; a++) g.mean[a] = mean[a] / g.n;
+    g.cov[0] = cov[0] / g.n; g.cov[1] = cov[1] / g.n; g.cov[2] = cov[2] / g.n; g.cov[3] = cov[4] / g.n; g.cov[4] = cov[5] / g.n; g.cov[5] = cov[8] / g.n;
+  }
   out[v] = g;
 }
 
@@ -634,8 +652,8 @@ int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int reg
   return PCM_OK;
 }
 
-int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgVoxel* d_out, std::string* err) {
-  k_vgicp_voxels<<<(map.num_voxels + 127) / 128, 128, 0, stream>>>(map.pts, map.vox_start, d_cov, map.num_voxels, d_out);
+int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, int mode, VgVoxel* d_out, std::string* err) {
+  k_vgicp_voxels<<<(map.num_voxels + 127) / 128, 128, 0, stream>>>(map.pts, map.vox_start, d_cov, map.num_voxels, mode, d_out);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { *err = std::string("k_vgicp_voxels: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
   return PCM_OK;

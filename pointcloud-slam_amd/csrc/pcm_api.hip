@@ -134,6 +134,7 @@ int validate_config(pcm_ctx* c, const pcm_config& g) {
     if (g.k_correspondences < 1 || g.k_correspondences > 64) { c->err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
     if (g.regularization < PCM_REG_NONE || g.regularization > PCM_REG_FROBENIUS) { c->err = "bad regularization method"; return PCM_ERR_INVALID_ARGUMENT; }
     if (!(g.max_corr_dist > 0.f)) { c->err = "max_corr_dist must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (g.voxel_mode < 0 || g.voxel_mode > 2) { c->err = "voxel_mode must be 0 (ADDITIVE), 1 (ADDITIVE_WEIGHTED) or 2 (MULTIPLICATIVE)"; return PCM_ERR_INVALID_ARGUMENT; }
   }
   if (g.optimizer != PCM_OPT_GAUSS_NEWTON && g.optimizer != PCM_OPT_LEVENBERG_MARQUARDT) { c->err = "bad optimizer"; return PCM_ERR_INVALID_ARGUMENT; }
   if (!(g.voxel_resolution > 0.f)) { c->err = "voxel_resolution must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
@@ -222,9 +223,9 @@ int prepare(pcm_ctx* c) {
   }
   if (gicp) {
     // FastGICP::computeTransformation: covariances of both clouds, lazily   fast_gicp_impl.hpp:102-110
-    if (c->cov_k != c->cfg.k_correspondences || c->cov_reg != c->cfg.regularization) {
+    if (c->cov_k != c->cfg.k_correspondences || c->cov_reg != c->cfg.regularization || c->cov_vmode != c->cfg.voxel_mode) {
       c->src_cov_valid = false; c->tgt_cov_valid = false;
-      c->cov_k = c->cfg.k_correspondences; c->cov_reg = c->cfg.regularization;
+      c->cov_k = c->cfg.k_correspondences; c->cov_reg = c->cfg.regularization; c->cov_vmode = c->cfg.voxel_mode;
     }
     if (!c->srcmap.valid || c->srcmap.res != c->cfg.voxel_resolution || c->srcmap.coord_mode != mode) {
       uint32_t n_src = (uint32_t)c->src.n;
@@ -248,7 +249,7 @@ int prepare(pcm_ctx* c) {
           HIPCK(c, hipMalloc(&c->vvox, sizeof(VgVoxel) * (size_t)c->map.num_voxels));
           c->vvox_cap = c->map.num_voxels;
         }
-        rc = build_vgicp_voxels(c->stream, c->map, c->tgt_cov, c->vvox, &c->err);
+        rc = build_vgicp_voxels(c->stream, c->map, c->tgt_cov, c->cfg.voxel_mode, c->vvox, &c->err);
         if (rc != PCM_OK) return rc;
       }
       c->tgt_cov_valid = true;

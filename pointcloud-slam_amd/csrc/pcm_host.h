@@ -96,7 +96,7 @@ void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_
 void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
 int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err);
-int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgVoxel* d_out, std::string* err);
+int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, int mode, VgVoxel* d_out, std::string* err);
 // pclndt.hip: pclomp NDT leaves and derivative passes (pass 0: score+gradient+Hessian, 1: score+gradient, 2: double Hessian only)
 int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err);
 int pclndt_workgroups(uint32_t n, uint32_t* per_out);
@@ -121,7 +121,7 @@ struct pcm_ctx {
   double* tgt_cov = nullptr;
   size_t src_cov_cap = 0, tgt_cov_cap = 0;
   bool src_cov_valid = false, tgt_cov_valid = false;
-  int cov_k = 0, cov_reg = -1;
+  int cov_k = 0, cov_reg = -1, cov_vmode = -1;
   pcm::VgVoxel* vvox = nullptr;
   size_t vvox_cap = 0;
   double* maha = nullptr;

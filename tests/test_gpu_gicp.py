@@ -19,7 +19,7 @@ def _both(pcm, model, optimizer, p, **kw):
     g = cls(0, optimizer=optimizer, **kw)
     cfg = g.config
     o = Oracle(model, optimizer, voxel_resolution=cfg.voxel_resolution, num_neighbors=cfg.num_neighbors,
-               max_corr_dist=float(cfg.max_corr_dist), k_correspondences=cfg.k_correspondences, regularization=cfg.regularization)
+               max_corr_dist=float(cfg.max_corr_dist), k_correspondences=cfg.k_correspondences, regularization=cfg.regularization, voxel_mode=cfg.voxel_mode)
     o.set_input_target(p.submap); o.set_input_source(p.scan)
     g.set_input_target(p.submap); g.set_input_source(p.scan)
     return o, g
@@ -55,7 +55,7 @@ def test_covariances_k_and_small_cloud(pcm, synth):
 
 
 @pytest.mark.parametrize("model,kw", [("GICP", {}), ("GICP", {"max_corr_dist": 0.3}), ("VGICP", {}), ("VGICP", {"num_neighbors": 7}),
-                                      ("VGICP", {"num_neighbors": 27, "voxel_resolution": 0.75})])
+                                      ("VGICP", {"num_neighbors": 27, "voxel_resolution": 0.75}), ("VGICP", {"num_neighbors": 7, "voxel_mode": 2, "regularization": "MIN_EIG"})])
 def test_linearize_matches_oracle(pcm, pair, model, kw):
     p = pair
     o, g = _both(pcm, model, "LM", p, **kw)
@@ -70,7 +70,7 @@ def test_linearize_matches_oracle(pcm, pair, model, kw):
 
 
 @pytest.mark.parametrize("model,optimizer,kw", [("GICP", "LM", {}), ("GICP", "GN", {"max_corr_dist": 1.0}), ("VGICP", "LM", {}),
-                                                ("VGICP", "GN", {"num_neighbors": 7})])
+                                                ("VGICP", "GN", {"num_neighbors": 7}), ("VGICP", "LM", {"voxel_mode": 2})])
 def test_align_matches_oracle(pcm, pair, model, optimizer, kw):
     from oracle.loader import result_T
     p = pair
