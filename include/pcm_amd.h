@@ -82,7 +82,7 @@ typedef struct pcm_config {
   double translation_eps;        /* 5e-4 (:13) */
   double lm_init_lambda_factor;  /* 1e-9 (:18) */
   float voxel_resolution;        /* iVox / voxel-map cell size [m] */
-  int32_t num_neighbors;         /* 1, 7, 19 or 27 cells searched around the query */
+  int32_t num_neighbors;         /* 1, 7, 19 or 27 cells searched around the query; pclomp NDT: 0 = KDTREE radius search */
   int32_t knn;                   /* NUM_MATCH_POINTS 5      jueying_lio/include/options.h:14 */
   int32_t min_knn;               /* MIN_NUM_MATCH_POINTS 3  jueying_lio/include/options.h:15 */
   float max_range;               /* GetClosestPoint max_range 5.0  jueying_lio/include/ivox3d/ivox3d.h:80 */

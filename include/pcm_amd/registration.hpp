@@ -221,8 +221,7 @@ public:
   void setStepSize(double s) { this->cfg_.ndt_step_size = static_cast<float>(s); }               // ndt_omp.h:166
   void setOulierRatio(double r) { this->cfg_.ndt_outlier_ratio = static_cast<float>(r); }        // ndt_omp.h:184 (sic)
   void setNeighborhoodSearchMethod(NeighborSearchMethodOmp m) {                                  // ndt_omp.h:198
-    if (m == KDTREE) throw std::runtime_error("pcm_amd::PclNdtRegistration: KDTREE neighbourhood search is not built");
-    this->cfg_.num_neighbors = m == DIRECT26 ? 27 : (m == DIRECT7 ? 7 : 1);
+    this->cfg_.num_neighbors = m == KDTREE ? 0 : (m == DIRECT26 ? 27 : (m == DIRECT7 ? 7 : 1));
   }
   double getTransformationProbability() const { return trans_probability_; }                     // ndt_omp.h:207
 protected:

@@ -27,7 +27,7 @@
 #include <omp.h>
 #endif
 
-typedef struct orc_leaf { double mean[3], cov[9], icov[9], evals[3]; double sum[3], sxx[9]; int n; } orc_leaf;
+typedef struct orc_leaf { double mean[3], cov[9], icov[9], evals[3]; double sum[3], sxx[9]; float csum[3], centroid[3]; int n, in_centroids; } orc_leaf;
 
 typedef struct orc_pclndt_state {
   orc_vhash h;
@@ -74,8 +74,11 @@ static void build_leaves(oracle *o) {
     if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
     const int c0 = (int)floorf(p[0] * s->inv_leaf), c1 = (int)floorf(p[1] * s->inv_leaf), c2 = (int)floorf(p[2] * s->inv_leaf);
     orc_leaf *l = &s->leaf[orc_vhash_insert(&s->h, c0, c1, c2)];
+    /* Leaf(): cov_ starts as the IDENTITY (voxel_grid_covariance_omp.h:103-110) and the first pass adds x x^T onto it (:236) */
+    if (l->n == 0) l->sxx[0] = l->sxx[4] = l->sxx[8] = 1.0;
     const double x[3] = {p[0], p[1], p[2]};
     for (int a = 0; a < 3; a++) { l->sum[a] += x[a]; for (int b = 0; b < 3; b++) l->sxx[a * 3 + b] += x[a] * x[b]; }
+    for (int a = 0; a < 3; a++) l->csum[a] += p[a];          /* leaf.centroid += pt (Vector4f, float)  :241-242 */
     l->n++;
   }
   s->nleaf = s->h.count;
@@ -83,8 +86,10 @@ static void build_leaves(oracle *o) {
   const double min_covar_eigvalue_mult = 0.01;             /* :211 */
   for (long v = 0; v < s->nleaf; v++) {                    /* second pass  :262-366 */
     orc_leaf *l = &s->leaf[v];
+    for (int a = 0; a < 3; a++) l->centroid[a] = l->csum[a] / (float)l->n;     /* :275 */
     for (int a = 0; a < 3; a++) l->mean[a] = l->sum[a] / l->n;
     if (l->n < min_points) continue;
+    l->in_centroids = 1;                                      /* pushed to the centroid cloud before the eigen checks  :288-318 */
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++)
       l->cov[a * 3 + b] = (l->sxx[a * 3 + b] - 2 * (l->sum[a] * l->mean[b])) / l->n + l->mean[a] * l->mean[b];      /* :323 */
     for (int a = 0; a < 9; a++) l->cov[a] *= (l->n - 1.0) / l->n;                                                 /* :324 */
@@ -111,6 +116,7 @@ static void build_leaves(oracle *o) {
 }
 
 static int neighbor_offsets(int nn, int out[27][3]) {
+  if (nn == 0) return 0;   /* KDTREE */
   if (nn == 1) { out[0][0] = out[0][1] = out[0][2] = 0; return 1; }
   if (nn == 7) {   /* getNeighborhoodAtPoint7  :414-428 */
     static const int o7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
@@ -122,10 +128,26 @@ static int neighbor_offsets(int nn, int out[27][3]) {
   return 27;
 }
 
-/* leaves around a transformed point  :373-405 (the bounding-box test only guards the linear index) */
+/* leaves around a transformed point  :373-405 (the bounding-box test only guards the linear index).
+ * nO == 0: KDTREE -- radiusSearch(point, resolution) over the centroid cloud (voxel_grid_covariance_omp.h:476-505): every leaf
+ * that entered the centroid cloud (>= 6 points, even if its covariance was rejected afterwards) whose float centroid lies
+ * strictly within the radius (FLANN RadiusResultSet: dist < radius^2, L2_Simple in float).  A centroid lies inside its own
+ * cell, so the 27 cells around the query hold every candidate. */
 static int neighborhood(const orc_pclndt_state *s, const float xt[3], int nO, int offs[27][3], const orc_leaf **out) {
   const int c0 = (int)floorf(xt[0] / s->leaf_size), c1 = (int)floorf(xt[1] / s->leaf_size), c2 = (int)floorf(xt[2] / s->leaf_size);
   int m = 0;
+  if (nO == 0) {
+    const float r2 = (float)((double)s->leaf_size * (double)s->leaf_size);
+    for (int i = -1; i <= 1; i++) for (int j = -1; j <= 1; j++) for (int k = -1; k <= 1; k++) {
+      const int v = orc_vhash_find(&s->h, c0 + i, c1 + j, c2 + k);
+      if (v < 0 || !s->leaf[v].in_centroids) continue;
+      const float *c = s->leaf[v].centroid;
+      float d2 = 0.0f;
+      for (int a = 0; a < 3; a++) { const float df = xt[a] - c[a]; d2 += df * df; }
+      if (d2 < r2) out[m++] = &s->leaf[v];
+    }
+    return m;
+  }
   for (int k = 0; k < nO; k++) {
     const int v = orc_vhash_find(&s->h, c0 + offs[k][0], c1 + offs[k][1], c2 + offs[k][2]);
     if (v >= 0 && s->leaf[v].n >= 6) out[m++] = &s->leaf[v];

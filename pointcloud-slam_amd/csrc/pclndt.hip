@@ -54,9 +54,12 @@ __global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict_
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
   const uint32_t p0 = vox_start[v], p1 = vox_start[v + 1];
-  double sum[3] = {0.0, 0.0, 0.0}, sxx[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  // Leaf(): cov_ starts as the IDENTITY and the first pass adds x x^T onto it (voxel_grid_covariance_omp.h:103-110, impl :236)
+  double sum[3] = {0.0, 0.0, 0.0}, sxx[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+  float csum[3] = {0.f, 0.f, 0.f};
   for (uint32_t p = p0; p < p1; p++) {
     const float4 c = pts[p];
+    csum[0] += c.x; csum[1] += c.y; csum[2] += c.z;   // leaf.centroid += pt (float)
     const double x[3] = {(double)c.x, (double)c.y, (double)c.z};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -67,6 +70,10 @@ __global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict_
   }
   PclLeaf L;
   int n = (int)(p1 - p0);
+  L.in_centroids = n >= 6 ? 1 : 0;
+  L.pad = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; a++) L.centroid[a] = csum[a] / (float)n;
 #pragma unroll
   for (int a = 0; a < 3; a++) L.mean[a] = sum[a] / n;
 #pragma unroll
@@ -115,7 +122,6 @@ __global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict_
     }
   }
   L.n = n;
-  L.pad = 0;
   out[v] = L;
 }
 
@@ -123,6 +129,26 @@ __device__ inline void ndt_offset3(int nO, int k, int& ox, int& oy, int& oz) {
   if (nO == 27) { ox = k / 9 - 1; oy = (k / 3) % 3 - 1; oz = k % 3 - 1; return; }   // pcl::getAllNeighborCellIndices order
   ox = oy = oz = 0;                                                                  // getNeighborhoodAtPoint7  :414-428
   if (k == 1) ox = 1; else if (k == 2) ox = -1; else if (k == 3) oy = 1; else if (k == 4) oy = -1; else if (k == 5) oz = 1; else if (k == 6) oz = -1;
+}
+
+// k-th neighbour leaf of the transformed point xt whose cell is (cx,cy,cz), or -1.  num_neighbors 1 / 7 / 27: the DIRECT
+// lookups (leaf must hold >= 6 points); 0: KDTREE = radiusSearch(point, resolution) over the centroid cloud
+// (voxel_grid_covariance_omp.h:476-505): float squared distance to the leaf's float centroid strictly below radius^2.
+__device__ inline int neighbour_leaf(const TargetView& tg, const PclLeaf* leaves, int nn, int k, int cx, int cy, int cz, const float (&xt)[3]) {
+  int ox, oy, oz;
+  ndt_offset3(nn == 0 ? 27 : nn, k, ox, oy, oz);
+  const int v = leaf_lookup(tg, cx + ox, cy + oy, cz + oz);
+  if (v < 0) return -1;
+  const PclLeaf* L = leaves + v;
+  if (nn == 0) {
+    if (*(const PCM_GLOBAL int32_t*)&L->in_centroids == 0) return -1;
+    const float r2 = (float)((double)tg.res * (double)tg.res);
+    float d2 = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { const float df = xt[a] - *(const PCM_GLOBAL float*)&L->centroid[a]; d2 += df * df; }
+    return d2 < r2 ? v : -1;
+  }
+  return *(const PCM_GLOBAL int32_t*)&L->n >= 6 ? v : -1;   // nr_points >= min_points_per_voxel_  :396
 }
 
 __device__ inline double wave_sum3(double v) {
@@ -184,13 +210,10 @@ __global__ void __launch_bounds__(256) k_pclndt_derivatives(TargetView tg, const
       for (int j = 0; j < 6; j++) pg[a][j] = (a == j) ? 1.0f : 0.0f;
     }
     pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
-    for (int k = 0; k < P.num_neighbors; k++) {
-      int ox, oy, oz;
-      ndt_offset3(P.num_neighbors, k, ox, oy, oz);
-      const int v = leaf_lookup(tg, cx + ox, cy + oy, cz + oz);
+    for (int k = 0; k < (P.num_neighbors == 0 ? 27 : P.num_neighbors); k++) {
+      const int v = neighbour_leaf(tg, leaves, P.num_neighbors, k, cx, cy, cz, xt);
       if (v < 0) continue;
       const PclLeaf* L = leaves + v;
-      if (*(const PCM_GLOBAL int32_t*)&L->n < 6) continue;   // nr_points >= min_points_per_voxel_  :396
       float xt4[3], ci[3][3];
 #pragma unroll
       for (int a = 0; a < 3; a++) xt4[a] = (float)((double)xt[a] - gload_d(&L->mean[a]));
@@ -281,13 +304,10 @@ __global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const Pcl
                  vc[3] = {0.0, PCM_DOT3(P.h_ang_d[4]), PCM_DOT3(P.h_ang_d[5])}, vd[3] = {PCM_DOT3(P.h_ang_d[6]), PCM_DOT3(P.h_ang_d[7]), PCM_DOT3(P.h_ang_d[8])},
                  ve[3] = {PCM_DOT3(P.h_ang_d[9]), PCM_DOT3(P.h_ang_d[10]), PCM_DOT3(P.h_ang_d[11])}, vf[3] = {PCM_DOT3(P.h_ang_d[12]), PCM_DOT3(P.h_ang_d[13]), PCM_DOT3(P.h_ang_d[14])};
 #undef PCM_DOT3
-    for (int k = 0; k < P.num_neighbors; k++) {
-      int ox, oy, oz;
-      ndt_offset3(P.num_neighbors, k, ox, oy, oz);
-      const int v = leaf_lookup(tg, cx + ox, cy + oy, cz + oz);
+    for (int k = 0; k < (P.num_neighbors == 0 ? 27 : P.num_neighbors); k++) {
+      const int v = neighbour_leaf(tg, leaves, P.num_neighbors, k, cx, cy, cz, xt);
       if (v < 0) continue;
       const PclLeaf* L = leaves + v;
-      if (*(const PCM_GLOBAL int32_t*)&L->n < 6) continue;
       double xt3[3], ic[9], cxv[3];
 #pragma unroll
       for (int a = 0; a < 3; a++) xt3[a] = (double)xt[a] - gload_d(&L->mean[a]);

@@ -124,7 +124,7 @@ bool is_gicp(int model) { return model == PCM_MODEL_GICP || model == PCM_MODEL_V
 int validate_config(pcm_ctx* c, const pcm_config& g) {
   if (g.model != PCM_MODEL_P2PLANE && !is_ndt(g.model) && !is_gicp(g.model) && g.model != PCM_MODEL_NDT_OMP) { c->err = "unknown registration model"; return PCM_ERR_UNSUPPORTED; }
   if (g.model == PCM_MODEL_NDT_OMP) {
-    if (g.num_neighbors == 19) { c->err = "pclomp NDT neighbourhoods are DIRECT1 / DIRECT7 / DIRECT26 (num_neighbors 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (g.num_neighbors == 19) { c->err = "pclomp NDT neighbourhoods are KDTREE / DIRECT1 / DIRECT7 / DIRECT26 (num_neighbors 0, 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT; }
     if (!(g.ndt_step_size > 0.f) || !(g.ndt_outlier_ratio > 0.f) || !(g.ndt_outlier_ratio < 1.f)) { c->err = "bad ndt_step_size / ndt_outlier_ratio"; return PCM_ERR_INVALID_ARGUMENT; }
   }
   if ((is_ndt(g.model) || g.model == PCM_MODEL_VGICP) && g.num_neighbors == 19) {
@@ -138,7 +138,7 @@ int validate_config(pcm_ctx* c, const pcm_config& g) {
   }
   if (g.optimizer != PCM_OPT_GAUSS_NEWTON && g.optimizer != PCM_OPT_LEVENBERG_MARQUARDT) { c->err = "bad optimizer"; return PCM_ERR_INVALID_ARGUMENT; }
   if (!(g.voxel_resolution > 0.f)) { c->err = "voxel_resolution must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
-  if (g.num_neighbors != 1 && g.num_neighbors != 7 && g.num_neighbors != 19 && g.num_neighbors != 27) {
+  if (g.num_neighbors != 1 && g.num_neighbors != 7 && g.num_neighbors != 19 && g.num_neighbors != 27 && !(g.model == PCM_MODEL_NDT_OMP && g.num_neighbors == 0)) {
     c->err = "num_neighbors must be 1, 7, 19 or 27"; return PCM_ERR_INVALID_ARGUMENT;
   }
   if (g.knn != 5 || g.min_knn != 3) { c->err = "knn/min_knn are the reference constants 5/3 (options.h:14-15)"; return PCM_ERR_UNSUPPORTED; }

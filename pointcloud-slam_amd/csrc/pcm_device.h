@@ -100,10 +100,12 @@ static_assert(sizeof(VgVoxel) == 80, "VgVoxel must be 80 bytes");
 struct PclLeaf {
   double mean[3];
   double icov[9];
-  int32_t n;        // nr_points; -1 when the covariance was rejected (impl :331-335, 353-357)
-  int32_t pad;
+  int32_t n;             // nr_points; -1 when the covariance was rejected (impl :331-335, 353-357)
+  int32_t in_centroids;  // 1: the leaf entered the centroid cloud the KDTREE search runs on (>= 6 points; before the rejections)
+  float centroid[3];     // leaf.centroid: float sum of the points / float(n)  (impl :241-242, 275)
+  float pad;
 };
-static_assert(sizeof(PclLeaf) == 104, "PclLeaf must be 104 bytes");
+static_assert(sizeof(PclLeaf) == 120, "PclLeaf must be 120 bytes");
 
 // Explicit global-address-space accessors.  Pointers that reach a kernel through a
 // descriptor struct are generic to the compiler; a generic (flat) load counts on

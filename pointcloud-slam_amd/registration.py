@@ -255,7 +255,8 @@ class VgicpRegistration(Registration):
 class PclNdtRegistration(Registration):
     """pclomp::NormalDistributionsTransform (pointcloud_match/ndt_omp/include/pclomp/ndt_omp_impl.hpp):
     Newton step with the analytic Hessian + More-Thuente line search on VoxelGridCovariance leaves;
-    defaults of that class: resolution 1.0, step 0.1, outlier ratio 0.55, epsilon 0.1, 35 iterations, DIRECT7 (:48,60-63)."""
+    defaults of that class: resolution 1.0, step 0.1, outlier ratio 0.55, epsilon 0.1, 35 iterations, DIRECT7 (:48,60-63).
+    ``num_neighbors``: 0 = KDTREE (radius search over the leaf centroids), 1 / 7 / 27 = DIRECT1 / DIRECT7 / DIRECT26."""
     model = "NDT_OMP"
     defaults = {"voxel_resolution": 1.0, "num_neighbors": 7, "max_iterations": 35, "translation_eps": 0.1}
 

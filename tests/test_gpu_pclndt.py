@@ -29,7 +29,7 @@ def _pvec(T):
     return np.concatenate([T[:3, 3], Rotation.from_matrix(T[:3, :3]).as_euler("XYZ")])
 
 
-@pytest.mark.parametrize("nn", [1, 7, 27])
+@pytest.mark.parametrize("nn", [0, 1, 7, 27])       # 0 = KDTREE (radius search over the leaf centroids), the default of jueying_slam's localization
 @pytest.mark.parametrize("res", [1.0, 0.5])
 def test_derivatives_match_oracle(pcm, pair_dense, nn, res):
     """computeDerivatives (float inner products) and computeHessian (double) at two poses."""
@@ -48,7 +48,7 @@ def test_derivatives_match_oracle(pcm, pair_dense, nn, res):
         assert rel_err(Hd1, Hd0) < 1e-9
 
 
-@pytest.mark.parametrize("nn,res", [(7, 1.0), (1, 1.0), (27, 1.0), (7, 0.5)])
+@pytest.mark.parametrize("nn,res", [(7, 1.0), (1, 1.0), (27, 1.0), (7, 0.5), (0, 1.0), (0, 0.5)])
 def test_align_matches_oracle(pcm, pair_dense, nn, res):
     from oracle.loader import result_T
     p = pair_dense

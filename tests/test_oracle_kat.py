@@ -276,7 +276,7 @@ def _blob_scene(seed=1):
     return tgt, src
 
 
-@pytest.mark.parametrize("nn", [1, 7, 27])
+@pytest.mark.parametrize("nn", [0, 1, 7, 27])
 def test_pclndt_oracle_derivatives_are_derivatives(nn):
     """orc_pclndt.c: gradient = d(score)/dp and Hessian = d(gradient)/dp (eq. 6.12 / 6.13) by central
     differences; the float-path Hessian equals the double-path one up to float rounding."""
@@ -314,7 +314,9 @@ def test_pclndt_oracle_pieces():
         if len(pts) < 6:
             continue
         assert np.allclose(leaf[0], pts.mean(axis=0), atol=1e-12)
-        cov = np.cov(pts.T, bias=True) * (len(pts) - 1.0) / len(pts)      # :323-324: biased estimate times (n-1)/n
+        # Leaf() starts cov_ as the identity (voxel_grid_covariance_omp.h:107), so the single-pass sum carries + I:
+        # :323-324: (biased estimate + I/n) times (n-1)/n
+        cov = (np.cov(pts.T, bias=True) + np.eye(3) / len(pts)) * (len(pts) - 1.0) / len(pts)
         w, V = np.linalg.eigh(cov)
         w = np.maximum(w, 0.01 * w[2])
         assert np.allclose(leaf[1], np.linalg.inv(V @ np.diag(w) @ V.T), rtol=1e-6)
