@@ -225,6 +225,9 @@ int pcm_get_target(pcm_ctx *ctx, float *out_xyz, size_t capacity_points, size_t 
  * (pointcloud_match/ndt_omp/include/pclomp/ndt_omp_impl.hpp:168-267, 498-559). */
 int pcm_ndt_derivatives(pcm_ctx *ctx, const double p[6], int pass, double *score, double g[6], double H[36]);
 
+/* pclomp NDT: calculateScore (ndt_omp_impl.hpp:835-880) of the source cloud transformed by T (row-major float 4x4) */
+int pcm_ndt_score(pcm_ctx *ctx, const float T[16], double *score);
+
 /* GICP / VGICP: regularised per-point covariances (row-major 3x3 doubles, INPUT order) of the source
  * (target = 0) or target (target = 1) cloud; computes them if needed.  Query the count with out = NULL.
  * Replaces FastGICP::getSourceCovariances / getTargetCovariances

@@ -81,6 +81,8 @@ def lib():
         L.orc_pclndt_derivatives.restype = C.c_double
         L.orc_pclndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_pclndt_hessian.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pclndt_score.restype = C.c_double
+        L.orc_pclndt_score.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_pclndt_leaf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.orc_pclndt_pose.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_pclndt_euler.argtypes = [C.c_void_p, C.c_void_p]
@@ -191,6 +193,10 @@ class Oracle:
         H = np.zeros((6, 6))
         lib().orc_pclndt_hessian(self._h, p.ctypes.data, H.ctypes.data)
         return H
+
+    def ndt_score(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        return lib().orc_pclndt_score(self._h, T.ctypes.data)
 
     def ndt_leaf(self, pt):
         pt = np.ascontiguousarray(pt, dtype=np.float32)

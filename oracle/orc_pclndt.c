@@ -579,6 +579,33 @@ done:
   return 0;
 }
 
+/* calculateScore  ndt_omp_impl.hpp:835-880: sum over the neighbour cells of (-d1 e - d3) / #cells, divided by N; double, serial */
+double orc_pclndt_score(void *h, const float T[16]) {
+  oracle *o = (oracle *)h;
+  orc_pclndt_state *s = ps(o);
+  build_leaves(o);
+  gauss_params(o);
+  int offs[27][3];
+  const int nO = neighbor_offsets(o->cfg.num_neighbors, offs);
+  double score = 0.0;
+  for (long idx = 0; idx < o->src.n; idx++) {
+    float xt[3];
+    transform_point(T, o->src.xyz + 3 * idx, xt);
+    const orc_leaf *nb[27];
+    const int m = neighborhood(s, xt, nO, offs, nb);
+    for (int c = 0; c < m; c++) {
+      const orc_leaf *l = nb[c];
+      double x[3], cx[3];
+      for (int a = 0; a < 3; a++) x[a] = (double)xt[a] - l->mean[a];
+      for (int a = 0; a < 3; a++) cx[a] = (l->icov[a * 3 + 0] * x[0] + l->icov[a * 3 + 1] * x[1]) + l->icov[a * 3 + 2] * x[2];
+      const double e = exp(-s->gauss_d2 * ((x[0] * cx[0] + x[1] * cx[1]) + x[2] * cx[2]) / 2);
+      const double inc = -s->gauss_d1 * e - s->gauss_d3;
+      score += inc / m;
+    }
+  }
+  return score / (double)o->src.n;
+}
+
 /* ---- unit hooks ------------------------------------------------------------------------------- */
 double orc_pclndt_derivatives(void *h, const double p[6], int compute_hessian, double g[6], double H[36]) {
   oracle *o = (oracle *)h;

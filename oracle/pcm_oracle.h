@@ -112,6 +112,7 @@ int orc_test_gauss_voxel(void *h, const float p[3], float mean[3], float cov[9],
  * line search evaluates them; the double-precision Hessian pass; a voxel leaf; small pieces */
 double orc_pclndt_derivatives(void *h, const double p[6], int compute_hessian, double g[6], double H[36]);
 void orc_pclndt_hessian(void *h, const double p[6], double H[36]);
+double orc_pclndt_score(void *h, const float T[16]);   /* calculateScore of the source transformed by T (row-major float) */
 int orc_pclndt_leaf(void *h, const float pt[3], double mean[3], double icov[9], int *n);
 void orc_pclndt_pose(const double p[6], float T[16]);
 void orc_pclndt_euler(const float R[9], float e[3]);

@@ -343,6 +343,46 @@ __global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const Pcl
   block_reduce_store<36>(acc, partials + (size_t)blockIdx.x * kNdtStride);
 }
 
+// ---------------------------------------------------------------------------
+// k_pclndt_score: calculateScore  :835-880 (double): sum over the neighbour cells of (-d1 e - d3) / #cells
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pclndt_score(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+                                                      double gauss_d3, double* __restrict__ partials) {
+  const uint32_t begin = blockIdx.x * per;
+  uint32_t end = begin + per;
+  end = end < n ? end : n;
+  double acc[1] = {0.0};
+  for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+    const float4 p = gload4(src + i);
+    float xt[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) xt[a] = P.T[a * 4 + 0] * p.x + (P.T[a * 4 + 1] * p.y + (P.T[a * 4 + 2] * p.z + P.T[a * 4 + 3]));
+    const float fx = floorf(xt[0] / tg.res), fy = floorf(xt[1] / tg.res), fz = floorf(xt[2] / tg.res);
+    const float lim = (float)(kCoordBias - 32);
+    if (!(fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim)) continue;
+    const int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    const int nk = P.num_neighbors == 0 ? 27 : P.num_neighbors;
+    int m = 0;
+    for (int k = 0; k < nk; k++) m += neighbour_leaf(tg, leaves, P.num_neighbors, k, cx, cy, cz, xt) >= 0 ? 1 : 0;
+    if (m == 0) continue;
+    double pt = 0.0;
+    for (int k = 0; k < nk; k++) {
+      const int v = neighbour_leaf(tg, leaves, P.num_neighbors, k, cx, cy, cz, xt);
+      if (v < 0) continue;
+      const PclLeaf* L = leaves + v;
+      double x[3], cxv[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) x[a] = (double)xt[a] - gload_d(&L->mean[a]);
+#pragma unroll
+      for (int a = 0; a < 3; a++) cxv[a] = (gload_d(&L->icov[a * 3 + 0]) * x[0] + gload_d(&L->icov[a * 3 + 1]) * x[1]) + gload_d(&L->icov[a * 3 + 2]) * x[2];
+      const double e = exp(-P.gauss_d2 * ((x[0] * cxv[0] + x[1] * cxv[1]) + x[2] * cxv[2]) / 2);
+      pt += (-P.gauss_d1 * e - gauss_d3) / m;
+    }
+    acc[0] += pt;
+  }
+  block_reduce_store<1>(acc, partials + (size_t)blockIdx.x * kNdtStride);
+}
+
 // fixed-order sum of the workgroup rows -> one row
 __global__ void __launch_bounds__(1024) k_pclndt_reduce(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
   __shared__ double s_grp[16][kNdtStride];
@@ -382,12 +422,14 @@ int pclndt_workgroups(uint32_t n, uint32_t* per_out) {
 }
 
 // one derivatives (or Hessian-only) pass; the 48-double result row lands in d_out
-void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out) {
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
+                        double gauss_d3) {
   uint32_t per = 0;
   const int nb = pclndt_workgroups(n, &per);
   if (pass == 0) k_pclndt_derivatives<true><<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
   else if (pass == 1) k_pclndt_derivatives<false><<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
-  else k_pclndt_hessian<<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
+  else if (pass == 2) k_pclndt_hessian<<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
+  else k_pclndt_score<<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, gauss_d3, d_partials);
   k_pclndt_reduce<<<1, 1024, 0, stream>>>(d_partials, nb, d_out);
 }
 

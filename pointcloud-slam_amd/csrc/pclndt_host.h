@@ -29,11 +29,13 @@ struct Solver {
   float resolution;
   int max_iterations, num_neighbors;
   NdtOmpParams P{};
+  double gauss_d3 = 0.0;
   int n_deriv = 0, n_hess = 0;
 
   void gauss_params() {   // eq. 6.8  :77-82
     const double c1 = 10 * (1 - outlier_ratio), c2 = outlier_ratio / std::pow((double)resolution, 3);
     const double d3 = -std::log(c2);
+    gauss_d3 = d3;
     P.gauss_d1 = -std::log(c1 + c2) - d3;
     P.gauss_d2 = -2 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / P.gauss_d1);
     P.num_neighbors = num_neighbors;

@@ -609,13 +609,14 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
 }
 
 // one pclomp NDT pass on the device: launch, read the 48-double row back (pass 0/1: H, g, score; pass 2: H)
-int pclndt_eval(pcm_ctx* c, int pass, const NdtOmpParams& P, ndtomp::Eval* e) {
-  launch_pclndt_pass(c->stream, c->map, c->pleaf, c->src.d_pts, (uint32_t)c->src.n, P, pass, c->ndt_partials, c->ndt_out);
+int pclndt_eval(pcm_ctx* c, int pass, const NdtOmpParams& P, ndtomp::Eval* e, double gauss_d3 = 0.0) {
+  launch_pclndt_pass(c->stream, c->map, c->pleaf, c->src.d_pts, (uint32_t)c->src.n, P, pass, c->ndt_partials, c->ndt_out, gauss_d3);
   HIPCK(c, hipGetLastError());
   HIPCK(c, hipMemcpyAsync(c->ndt_out_host, c->ndt_out, sizeof(double) * 48, hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
   std::memcpy(e->H, c->ndt_out_host, sizeof(double) * 36);
-  if (pass != 2) {
+  if (pass == 3) e->score = c->ndt_out_host[0];
+  else if (pass != 2) {
     std::memcpy(e->g, c->ndt_out_host + 36, sizeof(double) * 6);
     e->score = c->ndt_out_host[42];
   }
@@ -809,6 +810,25 @@ int pcm_clear_source(pcm_ctx* c) {
 int pcm_clear_target(pcm_ctx* c) {
   CHECK_CTX(c);
   c->tgt.n = 0; c->tgt.tag = 0; c->map.valid = false;
+  return PCM_OK;
+}
+
+// pclomp::NormalDistributionsTransform::calculateScore (ndt_omp_impl.hpp:835-880) of the source transformed by T
+int pcm_ndt_score(pcm_ctx* c, const float T[16], double* score) {
+  CHECK_CTX(c);
+  if (!T || !score) return PCM_ERR_INVALID_ARGUMENT;
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  if (c->cfg.model != PCM_MODEL_NDT_OMP) { c->err = "pcm_ndt_score needs the NDT_OMP model"; return PCM_ERR_UNSUPPORTED; }
+  rc = prepare(c);
+  if (rc != PCM_OK) return rc;
+  auto solver = make_ndt_solver(c);
+  solver.gauss_params();
+  std::memcpy(solver.P.T, T, sizeof(float) * 16);
+  ndtomp::Eval e{};
+  rc = pclndt_eval(c, 3, solver.P, &e, solver.gauss_d3);
+  if (rc != PCM_OK) return rc;
+  *score = e.score / (double)c->src.n;
   return PCM_OK;
 }
 

@@ -100,7 +100,8 @@ int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d
 // pclndt.hip: pclomp NDT leaves and derivative passes (pass 0: score+gradient+Hessian, 1: score+gradient, 2: double Hessian only)
 int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err);
 int pclndt_workgroups(uint32_t n, uint32_t* per_out);
-void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out);
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
+                        double gauss_d3 = 0.0);   // pass 3: calculateScore (needs gauss_d3)
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations, int window, unsigned int* d_queue);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
 

@@ -185,6 +185,13 @@ class Registration:
         self._check(self._L.pcm_ndt_derivatives(self._h, p.ctypes.data, mode, C.byref(score), g.ctypes.data, H.ctypes.data))
         return score.value, g, H
 
+    def ndt_score(self, T) -> float:
+        """pclomp NDT calculateScore of the source transformed by T (ndt_omp_impl.hpp:835-880)."""
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        s = C.c_double()
+        self._check(self._L.pcm_ndt_score(self._h, T.ctypes.data, C.byref(s)))
+        return s.value
+
     def get_covariances(self, target: bool = False) -> np.ndarray:
         """(N,3,3) regularised covariances of the source (or target) cloud, input order
         (FastGICP::getSourceCovariances / getTargetCovariances, fast_gicp.hpp:64-70)."""

@@ -46,6 +46,8 @@ def test_derivatives_match_oracle(pcm, pair_dense, nn, res):
         Hd0 = o.ndt_hessian(pv)
         _, _, Hd1 = g.ndt_derivatives(pv, "double")
         assert rel_err(Hd1, Hd0) < 1e-9
+        sc0, sc1 = o.ndt_score(T), g.ndt_score(T)          # calculateScore
+        assert sc0 != 0 and abs(sc1 - sc0) <= 1e-12 * abs(sc0)
 
 
 @pytest.mark.parametrize("nn,res", [(7, 1.0), (1, 1.0), (27, 1.0), (7, 0.5), (0, 1.0), (0, 0.5)])
