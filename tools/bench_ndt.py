@@ -9,7 +9,7 @@ ap.add_argument("--scan", type=int, default=100_000)
 ap.add_argument("--scans", type=int, default=8, help="scans registered against the one map (one batch)")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--cpu", type=int, default=1)
-ap.add_argument("--models", default="NDT_OMP,NDT_D2D,NDT_P2D")
+ap.add_argument("--models", default="NDT_OMP,NDT_OMP_KDTREE,NDT_D2D,NDT_P2D")
 a = ap.parse_args()
 synth = importlib.import_module("pointcloud-slam_amd.synth")
 scene = synth.scene_for_points(1234, a.map, 60.0)          # >6 points per 0.5 m voxel on surfaces
@@ -23,11 +23,13 @@ import torch
 import pointcloud_slam_amd as pcm
 d_map = torch.from_numpy(submap).cuda()
 out = {}
-for model in a.models.split(","):
+for mname in a.models.split(","):
+    model = "NDT_OMP" if mname.startswith("NDT_OMP") else mname
+    nn = 0 if mname == "NDT_OMP_KDTREE" else 7
     regs = []
     t0 = time.perf_counter()
     for sc in scans:
-        r = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=7) if model == "NDT_OMP" else pcm.NdtRegistration(0, model=model, voxel_resolution=0.5, num_neighbors=7)
+        r = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=nn) if model == "NDT_OMP" else pcm.NdtRegistration(0, model=model, voxel_resolution=0.5, num_neighbors=7)
         r.set_input_target(d_map); regs.append(r)
     d_scans = [torch.from_numpy(s).cuda() for s in scans]
     for r, s in zip(regs, d_scans):
@@ -41,13 +43,13 @@ for model in a.models.split(","):
         res = pcm.align_batch(regs, np.stack(guesses))
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.reps
     errs = [float(np.linalg.norm((np.linalg.inv(g) @ x.T64)[:3, 3])) for g, x in zip(gts, res)]
-    out[model] = {"registrations_per_s": a.scans / dt, "ms_per_batch": 1e3 * dt, "cold_s": t_cold, "iterations": [x.iterations for x in res], "evaluations": [x.num_linearize for x in res],
+    out[mname] = {"registrations_per_s": a.scans / dt, "ms_per_batch": 1e3 * dt, "cold_s": t_cold, "iterations": [x.iterations for x in res], "evaluations": [x.num_linearize for x in res],
                   "converged": [int(x.converged) for x in res], "err_vs_gt_m": [round(e, 3) for e in errs], "target_voxels": regs[0].stats()["target_voxels"]}
     if a.cpu:
         from oracle import Oracle
         from oracle.loader import result_T
         okw = dict(translation_eps=0.1, max_iterations=35) if model == "NDT_OMP" else {}
-        o = Oracle(model, "LM", voxel_resolution=0.5, num_neighbors=7, num_threads=min(16, len(os.sched_getaffinity(0))), **okw)
+        o = Oracle(model, "LM", voxel_resolution=0.5, num_neighbors=nn, num_threads=min(16, len(os.sched_getaffinity(0))), **okw)
         t0 = time.perf_counter(); o.set_input_target(submap); o.set_input_source(scans[0])
         if model == "NDT_OMP":
             o.ndt_leaf(submap[0, :3])
@@ -56,7 +58,7 @@ for model in a.models.split(","):
         t_build = time.perf_counter() - t0
         t0 = time.perf_counter(); ro = o.align(guesses[0]); t_al = time.perf_counter() - t0
         D = np.linalg.inv(result_T(ro)) @ res[0].T64
-        out[model]["cpu_oracle"] = {"build_s": t_build, "align_s": t_al, "registrations_per_s": 1.0 / t_al, "pose_diff_m": float(np.linalg.norm(D[:3, 3])),
+        out[mname]["cpu_oracle"] = {"build_s": t_build, "align_s": t_al, "registrations_per_s": 1.0 / t_al, "pose_diff_m": float(np.linalg.norm(D[:3, 3])),
                                     "pose_diff_rad": float(np.linalg.norm(D[:3, :3] - np.eye(3)))}
     del regs
 print(json.dumps(out, indent=1))
