@@ -49,6 +49,8 @@ typedef enum pcm_model {
   PCM_MODEL_VGICP = 2,   /* impl/fast_vgicp_impl.hpp:72-204, src/fast_gicp/cuda/compute_derivatives.cu */
   PCM_MODEL_NDT_P2D = 3, /* src/fast_gicp/cuda/ndt_compute_derivatives.cu:33-102 */
   PCM_MODEL_NDT_D2D = 4, /* src/fast_gicp/cuda/ndt_compute_derivatives.cu:104-175 */
+  PCM_MODEL_VGICP_CUDA = 6, /* FastVGICPCuda's float core: src/fast_gicp/cuda/{covariance_estimation,covariance_regularization,gaussian_voxelmap,
+                             * find_voxel_correspondences,compute_derivatives}.cu (resolution 1.0, DIRECT1, PLANE: impl/fast_vgicp_cuda_impl.hpp:24-27) */
   PCM_MODEL_NDT_OMP = 5  /* pclomp::NormalDistributionsTransform: pointcloud_match/ndt_omp/include/pclomp/ndt_omp_impl.hpp:69-880
                           * (Newton step + More-Thuente line search; max_iterations 35, translation_eps 0.1 = transformation_epsilon_,
                           *  voxel_resolution 1.0, num_neighbors 7 = DIRECT7 are that class's defaults) */

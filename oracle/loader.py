@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5}
+MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5, "VGICP_CUDA": 6}
 OPT = {"GN": 0, "LM": 1}
 REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
 
@@ -89,6 +89,7 @@ def lib():
         L.orc_pclndt_svd_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_test_knn_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_test_covariances.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_test_covariances_f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -212,6 +213,10 @@ class Oracle:
 
     def covariances(self, target=False):
         n = self._keep["t" if target else "s"].shape[0]
+        if self.cfg.model == MODEL["VGICP_CUDA"]:      # float CUDA-core semantics
+            outf = np.zeros((n, 3, 3), np.float32)
+            lib().orc_test_covariances_f(self._h, 1 if target else 0, outf.ctypes.data)
+            return outf.astype(np.float64)
         out = np.zeros((n, 3, 3))
         lib().orc_test_covariances(self._h, 1 if target else 0, out.ctypes.data)
         return out

@@ -148,6 +148,66 @@ void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs /* 9
   grid_free(&g);
 }
 
+/* ---- per-point covariances as the CUDA core computes them (float) ------------------------------
+ * covariance_estimation.cu:16-42 (sum pt, sum pt pt^T over the k neighbours, cov = S / k - mean mean^T)
+ * covariance_regularization.cu:14-121 (PLANE: V diag(1e-3, 1, 1) V^-1 with the eigenvectors of the self-adjoint solver,
+ * MIN_EIG, FROBENIUS; the other methods are "unimplemented" there and leave the covariance as it is).
+ * Neighbours: the CPU kd-tree of FastVGICPCuda (fast_vgicp_cuda_impl.hpp:97-101,152-170), k nearest incl. the point itself.
+ * Eigen's float computeDirect is replaced by the cyclic Jacobi in double, cast to float (same stand-in as the NDT voxels). */
+static void regularize_f(int method, float c[9]) {
+  if (method == ORC_REG_FROBENIUS) {
+    float C[9], Ci[9], N[9];
+    memcpy(C, c, sizeof(C));
+    C[0] += 1e-3f; C[4] += 1e-3f; C[8] += 1e-3f;
+    orc_inv3f(C, Ci);
+    float nrm = 0.0f;
+    for (int a = 0; a < 9; a++) nrm += Ci[a] * Ci[a];
+    nrm = sqrtf(nrm);
+    for (int a = 0; a < 9; a++) N[a] = Ci[a] / nrm;
+    orc_inv3f(N, c);
+    return;
+  }
+  if (method != ORC_REG_PLANE && method != ORC_REG_MIN_EIG) return;
+  double sym[9], w[3], V[9];
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sym[a * 3 + b] = (double)c[(a > b ? a : b) * 3 + (a > b ? b : a)];
+  orc_eig3_sym(sym, w, V);
+  float Vf[9], Vi[9], val[3], VD[9];
+  for (int a = 0; a < 9; a++) Vf[a] = (float)V[a];
+  if (method == ORC_REG_PLANE) { val[0] = 1e-3f; val[1] = 1.0f; val[2] = 1.0f; }
+  else for (int k = 0; k < 3; k++) val[k] = fmaxf(1e-3f, (float)w[k]);
+  orc_inv3f(Vf, Vi);
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) VD[a * 3 + b] = Vf[a * 3 + b] * val[b];
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) c[a * 3 + b] = (VD[a * 3 + 0] * Vi[0 * 3 + b] + VD[a * 3 + 1] * Vi[1 * 3 + b]) + VD[a * 3 + 2] * Vi[2 * 3 + b];
+}
+
+void orc_calc_covariances_f(const oracle *o, const orc_cloud *c, float *covs /* 9 per point */) {
+  orc_grid g;
+  memset(&g, 0, sizeof(g));
+  grid_build(&g, c, o->cfg.voxel_resolution);
+  const int k = o->cfg.k_correspondences;
+#ifdef _OPENMP
+  const int nth = o->cfg.num_threads > 0 ? o->cfg.num_threads : omp_get_max_threads();
+#else
+  const int nth = 1;
+#endif
+#pragma omp parallel for num_threads(nth) schedule(dynamic, 64)
+  for (long i = 0; i < c->n; i++) {
+    int idx[64];
+    float d2[64];
+    const int m = grid_knn(&g, c, c->xyz + 3 * i, k, 1e300, idx, d2);
+    float mean[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < m; j++) {
+      const float *pt = c->xyz + 3 * (long)idx[j];
+      for (int a = 0; a < 3; a++) { mean[a] += pt[a]; for (int b = 0; b < 3; b++) cov[a * 3 + b] += pt[a] * pt[b]; }
+    }
+    for (int a = 0; a < 3; a++) mean[a] /= (float)k;
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov[a * 3 + b] = cov[a * 3 + b] / (float)k - mean[a] * mean[b];
+    regularize_f(o->cfg.regularization, cov);
+    memcpy(covs + 9 * i, cov, sizeof(cov));
+  }
+  grid_free(&g);
+}
+
 /* ---- model state ---------------------------------------------------------------------------- */
 typedef struct orc_vgvox { double mean[3], cov[9]; int n; } orc_vgvox;
 
@@ -374,6 +434,11 @@ int orc_test_knn_exact(void *h, const float q[3], int k, int *idx, float *d2) {
   const int m = grid_knn(&g, &o->tgt, q, k, 1e300, idx, d2);
   grid_free(&g);
   return m;
+}
+
+void orc_test_covariances_f(void *h, int target, float *covs) {
+  oracle *o = (oracle *)h;
+  orc_calc_covariances_f(o, target ? &o->tgt : &o->src, covs);
 }
 
 void orc_test_covariances(void *h, int target, double *covs) {

@@ -81,5 +81,6 @@ void orc_gicp_invalidate(oracle *o, int target);
 void orc_gicp_swap(oracle *o);
 void orc_gicp_free(oracle *o);
 void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs);
+void orc_calc_covariances_f(const oracle *o, const orc_cloud *c, float *covs);   /* CUDA-core float semantics */
 
 #endif

@@ -46,6 +46,8 @@ typedef struct orc_gmap {
 
 typedef struct orc_gauss_state {
   orc_gmap tgt, src;
+  float *src_cov_f, *tgt_cov_f;   /* VGICP_CUDA: per-point float covariances (9 each) */
+  long src_cov_n, tgt_cov_n;
   int *corr;          /* [n_elems * n_offsets] target voxel index or -1, from the last linearize */
   long corr_cap;
   float lin_R[9];     /* linearized_x rotation (R_eval of the D2D kernel) */
@@ -124,6 +126,39 @@ static void gmap_build(orc_gmap *m, const orc_cloud *cl, float res) {
   m->valid = 1;
 }
 
+/* GaussianVoxelMap::create_voxelmap(points, covariances): voxel mean = mean of the points, voxel covariance = mean of
+ * the point covariances (accumulate_points_kernel + finalize_voxels_kernel, gaussian_voxelmap.cu:75-148,150-169) */
+static void gmap_build_vgc(orc_gmap *m, const orc_cloud *cl, float res, const float *covs) {
+  gmap_free(m);
+  const long n = cl->n;
+  orc_vhash_init(&m->h, n);
+  int *pv = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (long i = 0; i < n; i++) {
+    int c[3];
+    gauss_coord(res, cl->xyz + 3 * i, c);
+    pv[i] = orc_vhash_insert(&m->h, c[0], c[1], c[2]);
+  }
+  m->nvox = m->h.count;
+  double *sx = (double *)calloc((size_t)m->nvox * 3 + 1, sizeof(double));
+  double *sc = (double *)calloc((size_t)m->nvox * 9 + 1, sizeof(double));
+  int *cnt = (int *)calloc((size_t)m->nvox + 1, sizeof(int));
+  for (long i = 0; i < n; i++) {
+    const int v = pv[i];
+    cnt[v]++;
+    for (int a = 0; a < 3; a++) sx[v * 3 + a] += (double)cl->xyz[3 * i + a];
+    for (int a = 0; a < 9; a++) sc[v * 9 + a] += (double)covs[9 * i + a];
+  }
+  m->vox = (orc_gvox *)calloc((size_t)m->nvox + 1, sizeof(orc_gvox));
+  for (long v = 0; v < m->nvox; v++) {
+    orc_gvox *g = &m->vox[v];
+    g->n = cnt[v];
+    for (int a = 0; a < 3; a++) g->mean[a] = (float)(sx[v * 3 + a] / (double)cnt[v]);
+    for (int a = 0; a < 9; a++) g->cov[a] = (float)(sc[v * 9 + a] / (double)cnt[v]);
+  }
+  free(sx); free(sc); free(cnt); free(pv);
+  m->valid = 1;
+}
+
 static orc_gauss_state *gs(oracle *o) {
   if (!o->gauss) o->gauss = (orc_gauss_state *)calloc(1, sizeof(orc_gauss_state));
   return o->gauss;
@@ -131,12 +166,13 @@ static orc_gauss_state *gs(oracle *o) {
 
 void orc_gauss_invalidate(oracle *o, int target) {
   if (!o->gauss) return;
-  if (target) o->gauss->tgt.valid = 0; else o->gauss->src.valid = 0;
+  if (target) { o->gauss->tgt.valid = 0; o->gauss->tgt_cov_n = -1; } else { o->gauss->src.valid = 0; o->gauss->src_cov_n = -1; }
 }
 
 void orc_gauss_swap(oracle *o) {
   if (!o->gauss) return;
   orc_gmap t = o->gauss->tgt; o->gauss->tgt = o->gauss->src; o->gauss->src = t;
+  o->gauss->tgt.valid = 0; o->gauss->src.valid = 0; o->gauss->src_cov_n = -1; o->gauss->tgt_cov_n = -1;
   /* a map that was never built for the other role is simply rebuilt lazily */
 }
 
@@ -145,6 +181,7 @@ void orc_gauss_free(oracle *o) {
   gmap_free(&o->gauss->tgt);
   gmap_free(&o->gauss->src);
   free(o->gauss->corr);
+  free(o->gauss->src_cov_f); free(o->gauss->tgt_cov_f);
   free(o->gauss);
   o->gauss = NULL;
 }
@@ -153,6 +190,22 @@ void orc_gauss_free(oracle *o) {
 void orc_gauss_prepare(oracle *o) {
   orc_gauss_state *g = gs(o);
   const float res = (float)o->cfg.voxel_resolution;
+  if (o->cfg.model == ORC_MODEL_VGICP_CUDA) {   /* FastVGICPCuda: covariances of both clouds, voxel map of the target */
+    if (g->src_cov_n != o->src.n) {
+      free(g->src_cov_f);
+      g->src_cov_f = (float *)malloc(sizeof(float) * 9 * (size_t)(o->src.n + 1));
+      orc_calc_covariances_f(o, &o->src, g->src_cov_f);
+      g->src_cov_n = o->src.n;
+    }
+    if (g->tgt_cov_n != o->tgt.n || !g->tgt.valid) {
+      free(g->tgt_cov_f);
+      g->tgt_cov_f = (float *)malloc(sizeof(float) * 9 * (size_t)(o->tgt.n + 1));
+      orc_calc_covariances_f(o, &o->tgt, g->tgt_cov_f);
+      g->tgt_cov_n = o->tgt.n;
+      gmap_build_vgc(&g->tgt, &o->tgt, res, g->tgt_cov_f);
+    }
+    return;
+  }
   if (!g->tgt.valid) gmap_build(&g->tgt, &o->tgt, res);
   if (o->cfg.model == ORC_MODEL_NDT_D2D && !g->src.valid) gmap_build(&g->src, &o->src, res);
 }
@@ -171,6 +224,7 @@ static double ndt_pass(oracle *o, const double T[16], int update, double *H, dou
   orc_gauss_state *g = gs(o);
   orc_gauss_prepare(o);
   const int d2d = o->cfg.model == ORC_MODEL_NDT_D2D;
+  const int vgc = o->cfg.model == ORC_MODEL_VGICP_CUDA;   /* compute_derivatives.cu:49-92: the D2D form with per-point cov_A, w = sqrt(n), no Cauchy weight */
   const int nO = o->cfg.num_neighbors == 27 ? 27 : (o->cfg.num_neighbors == 1 ? 1 : 7);
   int offs[27][3];
   offsets_for(nO, offs);
@@ -213,11 +267,11 @@ static double ndt_pass(oracle *o, const double T[16], int update, double *H, dou
         }
         if (v < 0) continue;
         const orc_gvox *B = &g->tgt.vox[v];
-        if (B->n <= 6) continue;   /* ndt_compute_derivatives.cu:61,132 */
+        if (vgc ? B->n <= 0 : B->n <= 6) continue;   /* ndt_compute_derivatives.cu:61,132 | compute_derivatives.cu:62-64 */
         float C[9], M[9];
         memcpy(C, B->cov, sizeof(C));
-        if (d2d) {   /* RCR = R_eval * cov_A * R_eval^T ; M = (cov_B + RCR)^-1   :145-146 */
-          const float *CA = g->src.vox[i].cov;
+        if (d2d || vgc) {   /* RCR = R_eval * cov_A * R_eval^T ; M = (cov_B + RCR)^-1   :145-146 */
+          const float *CA = vgc ? g->src_cov_f + 9 * i : g->src.vox[i].cov;
           float RC[9];
           for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) RC[a * 3 + bb] = (Re[a * 3 + 0] * CA[0 * 3 + bb] + Re[a * 3 + 1] * CA[1 * 3 + bb]) + Re[a * 3 + 2] * CA[2 * 3 + bb];
           for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) C[a * 3 + bb] += (RC[a * 3 + 0] * Re[bb * 3 + 0] + RC[a * 3 + 1] * Re[bb * 3 + 1]) + RC[a * 3 + 2] * Re[bb * 3 + 2];
@@ -226,7 +280,7 @@ static double ndt_pass(oracle *o, const double T[16], int update, double *H, dou
         float e[3];
         for (int a = 0; a < 3; a++) e[a] = B->mean[a] - q[a];
         const float en = sqrtf((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
-        const float w = cauchy(res, en);                          /* :78,150 */
+        const float w = vgc ? sqrtf((float)B->n) : cauchy(res, en);   /* :78,150 | compute_derivatives.cu:78 */
         float Me[3];
         for (int a = 0; a < 3; a++) Me[a] = (M[a * 3 + 0] * e[0] + M[a * 3 + 1] * e[1]) + M[a * 3 + 2] * e[2];
         const float err = w * ((e[0] * Me[0] + e[1] * Me[1]) + e[2] * Me[2]);
@@ -261,7 +315,7 @@ static double ndt_pass(oracle *o, const double T[16], int update, double *H, dou
 
 double orc_gauss_linearize(oracle *o, const double T[16], double *H, double *b) {
   double Hl[36], bl[6];
-  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D) return orc_gicp_linearize(o, T, H, b);   /* orc_gicp.c */
+  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D && o->cfg.model != ORC_MODEL_VGICP_CUDA) return orc_gicp_linearize(o, T, H, b);   /* orc_gicp.c */
   const double c = ndt_pass(o, T, 1, Hl, bl);
   if (H) memcpy(H, Hl, sizeof(Hl));
   if (b) memcpy(b, bl, sizeof(bl));
@@ -269,7 +323,7 @@ double orc_gauss_linearize(oracle *o, const double T[16], double *H, double *b) 
 }
 
 double orc_gauss_compute_error(oracle *o, const double T[16]) {
-  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D) return orc_gicp_compute_error(o, T);
+  if (o->cfg.model != ORC_MODEL_NDT_P2D && o->cfg.model != ORC_MODEL_NDT_D2D && o->cfg.model != ORC_MODEL_VGICP_CUDA) return orc_gicp_compute_error(o, T);
   return ndt_pass(o, T, 0, NULL, NULL);
 }
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-enum { ORC_MODEL_P2PLANE = 0, ORC_MODEL_GICP = 1, ORC_MODEL_VGICP = 2, ORC_MODEL_NDT_P2D = 3, ORC_MODEL_NDT_D2D = 4, ORC_MODEL_NDT_OMP = 5 };
+enum { ORC_MODEL_P2PLANE = 0, ORC_MODEL_GICP = 1, ORC_MODEL_VGICP = 2, ORC_MODEL_NDT_P2D = 3, ORC_MODEL_NDT_D2D = 4, ORC_MODEL_NDT_OMP = 5, ORC_MODEL_VGICP_CUDA = 6 };
 enum { ORC_OPT_GN = 0, ORC_OPT_LM = 1 };
 enum { ORC_REG_NONE = 0, ORC_REG_MIN_EIG = 1, ORC_REG_NORMALIZED_MIN_EIG = 2, ORC_REG_PLANE = 3, ORC_REG_FROBENIUS = 4 };
 
@@ -121,6 +121,7 @@ void orc_pclndt_svd_solve(const double H[36], const double b[6], double x[6]);
 int orc_test_knn_exact(void *h, const float q[3], int k, int *idx, float *d2);
 /* regularised per-point covariances (9 doubles each) of the target (1) or source (0) cloud */
 void orc_test_covariances(void *h, int target, double *covs);
+void orc_test_covariances_f(void *h, int target, float *covs);   /* CUDA-core float semantics (9 floats per point) */
 
 #ifdef __cplusplus
 }

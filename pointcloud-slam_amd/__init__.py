@@ -9,5 +9,5 @@ library is missing, and contexts fail when no HIP device is present.
 """
 from .capi import PcmError, build_library, library_path, load_library  # noqa: F401
 from . import sharding  # noqa: F401
-from .registration import (GicpRegistration, NdtRegistration, P2PlaneRegistration, PclNdtRegistration, Registration, VgicpRegistration,  # noqa: F401
+from .registration import (GicpRegistration, NdtRegistration, P2PlaneRegistration, PclNdtRegistration, Registration, VgicpCudaRegistration, VgicpRegistration,  # noqa: F401
                            RegistrationResult, align_batch)

@@ -178,6 +178,54 @@ __device__ inline void regularize_cov(int method, const double (&cov)[9], double
   }
 }
 
+// covariance_regularization.cu:14-121 (float): PLANE / MIN_EIG through V diag V^-1 with the general inverse of the
+// eigenvector matrix, FROBENIUS; the other methods are unimplemented there and leave the matrix as it is.
+// (Eigen's float computeDirect is replaced by the cyclic Jacobi in double, cast to float.)
+__device__ inline void regularize_cov_f(int method, float (&c)[9]) {
+  if (method == PCM_REG_FROBENIUS) {
+    float C[9], Ci[9], N[9];
+#pragma unroll
+    for (int a = 0; a < 9; a++) C[a] = c[a];
+    C[0] += 1e-3f; C[4] += 1e-3f; C[8] += 1e-3f;
+    inv3<float>(C, Ci);
+    float nrm = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 9; a++) nrm += Ci[a] * Ci[a];
+    nrm = sqrtf(nrm);
+#pragma unroll
+    for (int a = 0; a < 9; a++) N[a] = Ci[a] / nrm;
+    inv3<float>(N, c);
+    return;
+  }
+  if (method != PCM_REG_PLANE && method != PCM_REG_MIN_EIG) return;
+  double sym[9], w[3], V[9];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) sym[a * 3 + b] = (double)c[(a > b ? a : b) * 3 + (a > b ? b : a)];
+  }
+  eig3_sym_jacobi(sym, w, V);
+  float Vf[9], Vi[9], val[3], VD[9];
+#pragma unroll
+  for (int a = 0; a < 9; a++) Vf[a] = (float)V[a];
+  if (method == PCM_REG_PLANE) { val[0] = 1e-3f; val[1] = 1.0f; val[2] = 1.0f; }
+  else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) val[k] = fmaxf(1e-3f, (float)w[k]);
+  }
+  inv3<float>(Vf, Vi);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) VD[a * 3 + b] = Vf[a * 3 + b] * val[b];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) c[a * 3 + b] = (VD[a * 3 + 0] * Vi[0 * 3 + b] + VD[a * 3 + 1] * Vi[1 * 3 + b]) + VD[a * 3 + 2] * Vi[2 * 3 + b];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k_covariances: one lane per map point, one wave per 64 CONSECUTIVE map points.  The map is
 // brick-major, so the 64 queries of a wave sit in neighbouring voxels and want nearly the same
@@ -378,6 +426,37 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
     }
   }
   if (!active) return;
+  if (reg >= 16) {
+    // CUDA-core semantics (PCM_MODEL_VGICP_CUDA): float sums over the neighbours nearest first, cov = S / k - mean mean^T
+    // (covariance_estimation.cu:16-42), float regularisation; the 9 floats of the (not exactly symmetric) result go into
+    // the point's 48-byte slot
+    float meanf[3] = {0.f, 0.f, 0.f}, cf[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KCAP; j++) {
+      if (j >= KCAP - k && bi[j] != ~0u) {
+        const float4 c = gload4(tg.pts + bi[j]);
+        const float x[3] = {c.x, c.y, c.z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          meanf[a] += x[a];
+#pragma unroll
+          for (int b = 0; b < 3; b++) cf[a * 3 + b] += x[a] * x[b];
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) meanf[a] /= (float)k;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) cf[a * 3 + b] = cf[a * 3 + b] / (float)k - meanf[a] * meanf[b];
+    }
+    regularize_cov_f(reg - 16, cf);
+    float* of = reinterpret_cast<float*>(out + (size_t)i * 6);
+#pragma unroll
+    for (int a = 0; a < 9; a++) gstore_f(of + a, cf[a]);
+    return;
+  }
   // neighbours (k columns; the mean and the covariance divide by k)  fast_gicp_impl.hpp:254-260
   double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -640,7 +719,7 @@ TargetView view_of(const TargetMap& m) {
 }  // namespace
 
 // regularised kNN covariance of every point of `map` (map order), 6 doubles each
-int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err) {
+int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err) {   // regularization + 16: CUDA-core float semantics
   if (k < 1 || k > 64) { *err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
   const size_t lds = 4 * (size_t)kWaveLds;
   const dim3 grid((map.num_points + 255) / 256);
@@ -649,6 +728,38 @@ int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int reg
   else k_covariances<64><<<grid, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { *err = std::string("k_covariances: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return PCM_OK;
+}
+
+// GaussianVoxelMap::create_voxelmap(points, covariances) of the CUDA core: voxel mean = mean of its points, voxel covariance =
+// mean of the point covariances (gaussian_voxelmap.cu:75-169); sums in double, input order (the reference: float atomics)
+__global__ void __launch_bounds__(128) k_vgc_voxels(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, const double* __restrict__ covs, uint32_t nvox,
+                                                    VgcVoxel* __restrict__ out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t p0 = vox_start[v], p1 = vox_start[v + 1];
+  double sx[3] = {0.0, 0.0, 0.0}, sc[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (uint32_t p = p0; p < p1; p++) {
+    const float4 c = pts[p];
+    sx[0] += (double)c.x; sx[1] += (double)c.y; sx[2] += (double)c.z;
+    const float* cf = reinterpret_cast<const float*>(covs + (size_t)p * 6);
+#pragma unroll
+    for (int a = 0; a < 9; a++) sc[a] += (double)cf[a];
+  }
+  VgcVoxel g;
+  g.n = (int32_t)(p1 - p0);
+#pragma unroll
+  for (int a = 0; a < 3; a++) g.mean[a] = (float)(sx[a] / (double)g.n);
+#pragma unroll
+  for (int a = 0; a < 9; a++) g.cov[a] = (float)(sc[a] / (double)g.n);
+  g.pad[0] = g.pad[1] = g.pad[2] = 0.f;
+  out[v] = g;
+}
+
+int build_vgc_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgcVoxel* d_out, std::string* err) {
+  k_vgc_voxels<<<(map.num_voxels + 127) / 128, 128, 0, stream>>>(map.pts, map.vox_start, d_cov, map.num_voxels, d_out);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { *err = std::string("k_vgc_voxels: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
   return PCM_OK;
 }
 

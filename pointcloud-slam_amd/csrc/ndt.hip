@@ -84,11 +84,12 @@ __device__ inline double wave_sum_d(double v) {
 //        TRIAL = true  -> cost of the remembered correspondences at xi (compute_error)
 // grid = (blocks_per_pair, npairs), block = 256, kp.lin_points_per_block elements per workgroup
 // ---------------------------------------------------------------------------
-template <bool D2D, bool TRIAL>
+template <int KIND, bool TRIAL>   // KIND 0: NDT P2D, 1: NDT D2D, 2: VGICP of the CUDA core (compute_derivatives.cu:49-92)
 __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
   const int pair = PCM_PAIR_OF(kp, blockIdx.y);
   const int mode = states[pair].mode;
   if (mode != (TRIAL ? MODE_TRIAL : MODE_LINEARIZE)) return;
+  constexpr bool D2D = KIND == 1, VGC = KIND == 2;
   const PairDesc d = descs[pair];
   const uint32_t per = (uint32_t)(TRIAL ? kp.points_per_block : kp.lin_points_per_block);
   const uint32_t begin = blockIdx.x * per;
@@ -118,6 +119,12 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
     if (D2D) {
       int na;
       load_gvox(d.src.gvox + i, pa, CA, na);
+    } else if (VGC) {   // source element = point i of the brick-major copy, its 9-float covariance in the 48-byte slot
+      const float4 p = gload4(d.src.pts + i);
+      pa[0] = p.x; pa[1] = p.y; pa[2] = p.z;
+      const float* cf = reinterpret_cast<const float*>(d.src_cov + (size_t)i * 6);
+#pragma unroll
+      for (int a = 0; a < 9; a++) CA[a] = *(const PCM_GLOBAL float*)(cf + a);
     } else {
       const float4 p = gload4(d.src.pts + i);
       pa[0] = p.x; pa[1] = p.y; pa[2] = p.z;
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
       if (inrange) { cx = (int)fx; cy = (int)fy; cz = (int)fz; }
     }
     float RCR[9];
-    if (D2D) {   // RCR = R_eval cov_A R_eval^T   ndt_compute_derivatives.cu:145
+    if (D2D || VGC) {   // RCR = R_eval cov_A R_eval^T   ndt_compute_derivatives.cu:145 | compute_derivatives.cu:75
       float RC[9];
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -163,9 +170,18 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
       if (v < 0) continue;
       float mb[3], C[9];
       int nb;
-      load_gvox(tg.gvox + v, mb, C, nb);
-      if (nb <= 6) continue;   // ndt_compute_derivatives.cu:61,132
-      if (D2D) {
+      if (VGC) {
+        const VgcVoxel* cv = d.cvox + v;
+        const float4 a0 = gload4(reinterpret_cast<const float4*>(cv)), a1 = gload4(reinterpret_cast<const float4*>(cv) + 1), a2 = gload4(reinterpret_cast<const float4*>(cv) + 2);
+        mb[0] = a0.x; mb[1] = a0.y; mb[2] = a0.z; nb = __float_as_int(a0.w);
+        C[0] = a1.x; C[1] = a1.y; C[2] = a1.z; C[3] = a1.w; C[4] = a2.x; C[5] = a2.y; C[6] = a2.z; C[7] = a2.w;
+        C[8] = *(const PCM_GLOBAL float*)&cv->cov[8];
+        if (nb <= 0) continue;   // compute_derivatives.cu:62-64
+      } else {
+        load_gvox(tg.gvox + v, mb, C, nb);
+        if (nb <= 6) continue;   // ndt_compute_derivatives.cu:61,132
+      }
+      if (D2D || VGC) {
 #pragma unroll
         for (int a = 0; a < 9; a++) C[a] += RCR[a];
       }
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
       for (int a = 0; a < 3; a++) e[a] = mb[a] - q[a];
       const float en = sqrtf((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
       const float ksq = tg.res * tg.res;
-      const float w = ksq / (ksq + en * en);                       // cauchy(resolution, |e|)  :15-18,78,150
+      const float w = VGC ? sqrtf((float)nb) : ksq / (ksq + en * en);   // cauchy(resolution, |e|)  :15-18,78,150 | sqrtf(num_points)  compute_derivatives.cu:78
       float Me[3];
 #pragma unroll
       for (int a = 0; a < 3; a++) Me[a] = (M[a * 3 + 0] * e[0] + M[a * 3 + 1] * e[1]) + M[a * 3 + 2] * e[2];
@@ -217,14 +233,17 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
   }
 }
 
-void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool d2d, bool trial) {
+void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, int kind, bool trial) {
   dim3 grid((unsigned)(trial ? kp.blocks_per_pair : kp.tiles_per_pair), (unsigned)npairs);
-  if (d2d) {
-    if (trial) k_ndt<true, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
-    else k_ndt<true, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+  if (kind == 1) {
+    if (trial) k_ndt<1, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+    else k_ndt<1, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+  } else if (kind == 2) {
+    if (trial) k_ndt<2, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+    else k_ndt<2, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
   } else {
-    if (trial) k_ndt<false, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
-    else k_ndt<false, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+    if (trial) k_ndt<0, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
+    else k_ndt<0, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp);
   }
 }
 

@@ -119,7 +119,8 @@ int coord_mode_for(int model) {
 size_t num_elements(const pcm_ctx* c) { return c->cfg.model == PCM_MODEL_NDT_D2D ? (size_t)c->srcmap.num_voxels : c->src.n; }
 
 bool is_ndt(int model) { return model == PCM_MODEL_NDT_P2D || model == PCM_MODEL_NDT_D2D; }
-bool is_gicp(int model) { return model == PCM_MODEL_GICP || model == PCM_MODEL_VGICP; }
+bool is_gicp(int model) { return model == PCM_MODEL_GICP || model == PCM_MODEL_VGICP || model == PCM_MODEL_VGICP_CUDA; }   // models with per-point covariances
+int ndt_kind(int model) { return model == PCM_MODEL_NDT_D2D ? 1 : (model == PCM_MODEL_VGICP_CUDA ? 2 : 0); }
 
 int validate_config(pcm_ctx* c, const pcm_config& g) {
   if (g.model != PCM_MODEL_P2PLANE && !is_ndt(g.model) && !is_gicp(g.model) && g.model != PCM_MODEL_NDT_OMP) { c->err = "unknown registration model"; return PCM_ERR_UNSUPPORTED; }
@@ -127,7 +128,7 @@ int validate_config(pcm_ctx* c, const pcm_config& g) {
     if (g.num_neighbors == 19) { c->err = "pclomp NDT neighbourhoods are KDTREE / DIRECT1 / DIRECT7 / DIRECT26 (num_neighbors 0, 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT; }
     if (!(g.ndt_step_size > 0.f) || !(g.ndt_outlier_ratio > 0.f) || !(g.ndt_outlier_ratio < 1.f)) { c->err = "bad ndt_step_size / ndt_outlier_ratio"; return PCM_ERR_INVALID_ARGUMENT; }
   }
-  if ((is_ndt(g.model) || g.model == PCM_MODEL_VGICP) && g.num_neighbors == 19) {
+  if ((is_ndt(g.model) || g.model == PCM_MODEL_VGICP || g.model == PCM_MODEL_VGICP_CUDA) && g.num_neighbors == 19) {
     c->err = "NDT / VGICP neighbourhoods are DIRECT1 / DIRECT7 / DIRECT27 (num_neighbors 1, 7, 27)"; return PCM_ERR_INVALID_ARGUMENT;
   }
   if (is_gicp(g.model)) {
@@ -223,9 +224,9 @@ int prepare(pcm_ctx* c) {
   }
   if (gicp) {
     // FastGICP::computeTransformation: covariances of both clouds, lazily   fast_gicp_impl.hpp:102-110
-    if (c->cov_k != c->cfg.k_correspondences || c->cov_reg != c->cfg.regularization || c->cov_vmode != c->cfg.voxel_mode) {
+    if (c->cov_k != c->cfg.k_correspondences || c->cov_reg != c->cfg.regularization + 100 * c->cfg.model || c->cov_vmode != c->cfg.voxel_mode) {
       c->src_cov_valid = false; c->tgt_cov_valid = false;
-      c->cov_k = c->cfg.k_correspondences; c->cov_reg = c->cfg.regularization; c->cov_vmode = c->cfg.voxel_mode;
+      c->cov_k = c->cfg.k_correspondences; c->cov_reg = c->cfg.regularization + 100 * c->cfg.model; c->cov_vmode = c->cfg.voxel_mode;
     }
     if (!c->srcmap.valid || c->srcmap.res != c->cfg.voxel_resolution || c->srcmap.coord_mode != mode) {
       uint32_t n_src = (uint32_t)c->src.n;
@@ -240,11 +241,23 @@ int prepare(pcm_ctx* c) {
         HIPCK(c, hipMalloc(&c->tgt_cov, sizeof(double) * 6 * (size_t)c->map.num_points));
         c->tgt_cov_cap = c->map.num_points;
       }
-      int rc = compute_covariances(c->stream, c->map, c->cfg.k_correspondences, c->cfg.regularization, c->tgt_cov, &c->err);
+      const int reg_code = c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0);   // + 16: float CUDA-core semantics
+      int rc = compute_covariances(c->stream, c->map, c->cfg.k_correspondences, reg_code, c->tgt_cov, &c->err);
       if (rc != PCM_OK) return rc;
+      if (c->cfg.model == PCM_MODEL_VGICP_CUDA) {
+        if (c->cvox_cap < c->map.num_voxels) {
+          if (c->cvox) hipFree(c->cvox);
+          c->cvox = nullptr; c->cvox_cap = 0;
+          HIPCK(c, hipMalloc(&c->cvox, sizeof(VgcVoxel) * (size_t)c->map.num_voxels));
+          c->cvox_cap = c->map.num_voxels;
+        }
+        rc = build_vgc_voxels(c->stream, c->map, c->tgt_cov, c->cvox, &c->err);
+        if (rc != PCM_OK) return rc;
+      }
       if (c->cfg.model == PCM_MODEL_VGICP) {
         if (c->vvox_cap < c->map.num_voxels) {
           if (c->vvox) hipFree(c->vvox);
+    if (c->cvox) hipFree(c->cvox);
           c->vvox = nullptr; c->vvox_cap = 0;
           HIPCK(c, hipMalloc(&c->vvox, sizeof(VgVoxel) * (size_t)c->map.num_voxels));
           c->vvox_cap = c->map.num_voxels;
@@ -261,11 +274,11 @@ int prepare(pcm_ctx* c) {
         HIPCK(c, hipMalloc(&c->src_cov, sizeof(double) * 6 * (size_t)c->srcmap.num_points));
         c->src_cov_cap = c->srcmap.num_points;
       }
-      int rc = compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization, c->src_cov, &c->err);
+      int rc = compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0), c->src_cov, &c->err);
       if (rc != PCM_OK) return rc;
       c->src_cov_valid = true;
     }
-    const size_t ncorr = c->src.n * (size_t)(c->cfg.model == PCM_MODEL_VGICP ? c->cfg.num_neighbors : 1);
+    const size_t ncorr = c->cfg.model == PCM_MODEL_VGICP_CUDA ? 0 : c->src.n * (size_t)(c->cfg.model == PCM_MODEL_VGICP ? c->cfg.num_neighbors : 1);
     if (c->maha_cap < ncorr) {
       if (c->maha) hipFree(c->maha);
     if (c->pleaf) hipFree(c->pleaf);
@@ -353,6 +366,7 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->src_cov = c->src_cov;
   d->tgt_cov = c->tgt_cov;
   d->vvox = c->vvox;
+  d->cvox = c->cvox;
   d->maha = c->maha;
   d->src.gvox = c->srcmap.gvox;
   d->src.num_points = (uint32_t)num_elements(c);
@@ -380,7 +394,7 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.tiles_per_pair = geom.tiles_per_pair;
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
   kp.do_step = 1;
-  kp.lin_points_per_block = is_ndt(g.model) ? geom.points_per_block : 256;
+  kp.lin_points_per_block = (is_ndt(g.model) || g.model == PCM_MODEL_VGICP_CUDA) ? geom.points_per_block : 256;
   kp.coord_mode = coord_mode_for(g.model);
   kp.max_corr_sq = (double)g.max_corr_dist * (double)g.max_corr_dist;
   return kp;
@@ -427,8 +441,8 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     for (int i = 0; i < n; i++) HIPCK(c0, hipStreamSynchronize(ctxs[i]->stream));
   }
   const pcm_config& g = c0->cfg;
-  const bool ndt = is_ndt(g.model);
-  const bool gicp = is_gicp(g.model);
+  const bool ndt = is_ndt(g.model) || g.model == PCM_MODEL_VGICP_CUDA;   // residual kernel of the Gaussian-voxel family
+  const bool gicp = is_gicp(g.model);                                     // per-point covariances, source elements = brick-major copy
   const Geom geom = pick_geom(max_n, n, ndt);
   const LsqParams lp = lsq_params(g);
   const KernelParams kp = kernel_params(g, geom);
@@ -497,13 +511,13 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     }
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
-    if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_NDT_D2D, false);
+    if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), false);
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
     launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
     if (is_lm) {
-      if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_NDT_D2D, true);
+      if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), true);
       else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, true);
       else launch_trial(st, w->d_descs, w->d_states, kpr, nl);
       launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, true, true, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
@@ -580,7 +594,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   if (c->cfg.model == PCM_MODEL_NDT_OMP) { c->err = "the pclomp NDT model is evaluated through pcm_ndt_derivatives"; return PCM_ERR_UNSUPPORTED; }
   int rc = prepare(c);
   if (rc != PCM_OK) return rc;
-  const bool ndt = is_ndt(c->cfg.model);
+  const bool ndt = is_ndt(c->cfg.model) || c->cfg.model == PCM_MODEL_VGICP_CUDA;
   const Geom geom = pick_geom(num_elements(c), 1, ndt);
   const KernelParams kp = kernel_params(c->cfg, geom);
   Workspace* w = nullptr;
@@ -597,7 +611,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   HIPCK(c, hipMemcpyAsync(w->d_states, &s, sizeof(s), hipMemcpyHostToDevice, c->stream));
   KernelParams kp1 = kp;
   kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
-  if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_NDT_D2D, !linearize);
+  if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, ndt_kind(c->cfg.model), !linearize);
   else if (is_gicp(c->cfg.model)) launch_gicp(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_VGICP, !linearize);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
@@ -726,6 +740,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->src_cov) hipFree(c->src_cov);
     if (c->tgt_cov) hipFree(c->tgt_cov);
     if (c->vvox) hipFree(c->vvox);
+    if (c->cvox) hipFree(c->cvox);
     if (c->maha) hipFree(c->maha);
     if (c->pleaf) hipFree(c->pleaf);
     if (c->ndt_partials) hipFree(c->ndt_partials);
@@ -853,6 +868,11 @@ int pcm_get_covariances(pcm_ctx* c, int target, double* out, size_t capacity_poi
   for (size_t i = 0; i < ord.size(); i++) {
     const double* s = &h6[i * 6];
     double* o = out + (size_t)ord[i] * 9;
+    if (c->cfg.model == PCM_MODEL_VGICP_CUDA) {   // the slot holds the 9 floats of the CUDA-core covariance
+      const float* f = reinterpret_cast<const float*>(s);
+      for (int a = 0; a < 9; a++) o[a] = (double)f[a];
+      continue;
+    }
     o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[1]; o[4] = s[3]; o[5] = s[4]; o[6] = s[2]; o[7] = s[4]; o[8] = s[5];
   }
   return PCM_OK;

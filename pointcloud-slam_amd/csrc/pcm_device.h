@@ -95,6 +95,17 @@ struct VgVoxel {
 };
 static_assert(sizeof(VgVoxel) == 80, "VgVoxel must be 80 bytes");
 
+// voxel payload of the CUDA-core VGICP model (PCM_MODEL_VGICP_CUDA): float mean, full 3x3 float covariance (the mean of
+// the point covariances, which are V diag V^-1 products and not exactly symmetric), point count
+// (fast_gicp/include/fast_gicp/cuda/gaussian_voxelmap.cuh:36-38)
+struct VgcVoxel {
+  float mean[3];
+  int32_t n;
+  float cov[9];
+  float pad[3];
+};
+static_assert(sizeof(VgcVoxel) == 64, "VgcVoxel must be 64 bytes");
+
 // pclomp VoxelGridCovariance::Leaf as the NDT derivatives read it (mean_, icov_, nr_points; doubles)
 // ndt_omp/include/pclomp/voxel_grid_covariance_omp.h:90-190
 struct PclLeaf {
@@ -189,6 +200,7 @@ struct PairDesc {
   const double* src_cov;   // GICP / VGICP: [N][6] regularised covariance of every source point (xx xy xz yy yz zz)
   const double* tgt_cov;   // GICP: [M][6] of every map point (map order)
   const VgVoxel* vvox;     // VGICP: voxel distributions, same order as vox_start
+  const VgcVoxel* cvox;    // VGICP_CUDA: float voxel distributions
   double* maha;            // GICP / VGICP: [correspondence][6] (cov_B + R cov_A R^T)^-1 of the last linearize
   double* partials;     // [workgroups of the round][kPartialStride]
   unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)

@@ -92,11 +92,12 @@ void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks
 void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs);
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
                          bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue = nullptr, int total_pairs = 0);
-void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool d2d, bool trial);
+void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, int kind, bool trial);   // kind 0 P2D, 1 D2D, 2 VGICP_CUDA
 void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
 int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err);
 int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, int mode, VgVoxel* d_out, std::string* err);
+int build_vgc_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgcVoxel* d_out, std::string* err);
 // pclndt.hip: pclomp NDT leaves and derivative passes (pass 0: score+gradient+Hessian, 1: score+gradient, 2: double Hessian only)
 int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err);
 int pclndt_workgroups(uint32_t n, uint32_t* per_out);
@@ -125,6 +126,8 @@ struct pcm_ctx {
   int cov_k = 0, cov_reg = -1, cov_vmode = -1;
   pcm::VgVoxel* vvox = nullptr;
   size_t vvox_cap = 0;
+  pcm::VgcVoxel* cvox = nullptr;   // VGICP_CUDA
+  size_t cvox_cap = 0;
   double* maha = nullptr;
   size_t maha_cap = 0;
   // pclomp NDT: leaf payload of the map, partial rows, result row (device + pinned host)

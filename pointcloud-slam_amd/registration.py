@@ -271,6 +271,13 @@ class PclNdtRegistration(Registration):
     def set_outlier_ratio(self, r): self._set(ndt_outlier_ratio=float(r))          # setOulierRatio    ndt_omp.h
 
 
+class VgicpCudaRegistration(Registration):
+    """FastVGICPCuda's float core (fast_gicp/src/fast_gicp/cuda/*.cu behind impl/fast_vgicp_cuda_impl.hpp): float 20-NN
+    covariances and voxel distributions, D2D cost with w = sqrt(n); resolution 1.0, DIRECT1, PLANE (:24-27)."""
+    model = "VGICP_CUDA"
+    defaults = {"voxel_resolution": 1.0, "num_neighbors": 1}
+
+
 class NdtRegistration(Registration):
     """NDT on Gaussian voxels with the reference NDTCuda's semantics
     (fast_gicp/include/fast_gicp/ndt/ndt_cuda.hpp:21-71, src/fast_gicp/cuda/ndt_cuda.cu):
