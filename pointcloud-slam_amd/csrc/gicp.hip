@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(256) k_gicp(const PairDesc* __restrict__ descs
 #pragma unroll
       for (int r = 0; r < 6; r++) {
 #pragma unroll
-        for (int cc = r; cc < 6; cc++) { acc[tt] += w * (JtM[r][0] * J[0][cc] + JtM[r][1] * J[1][cc] + JtM[r][2] * J[2][cc]); tt++; }
+        for (int cc = r; cc < 6; cc++) { acc[tt] += w * (JtM[cc][0] * J[0][r] + JtM[cc][1] * J[1][r] + JtM[cc][2] * J[2][r]); tt++; }   // entry (cc, r): the lower triangle, which the reference's LDLT reads
       }
 #pragma unroll
       for (int r = 0; r < 6; r++) acc[21 + r] += w * (JtM[r][0] * e[0] + JtM[r][1] * e[1] + JtM[r][2] * e[2]);

@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
 #pragma unroll
       for (int r = 0; r < 6; r++) {
 #pragma unroll
-        for (int c = r; c < 6; c++) { acc[tt] += (double)((JtM[r][0] * J[0][c] + JtM[r][1] * J[1][c]) + JtM[r][2] * J[2][c]); tt++; }
+        for (int c = r; c < 6; c++) { acc[tt] += (double)((JtM[c][0] * J[0][r] + JtM[c][1] * J[1][r]) + JtM[c][2] * J[2][r]); tt++; }   // entry (c, r) of the float product: the LOWER triangle is what the LDLT of the reference reads
       }
 #pragma unroll
       for (int r = 0; r < 6; r++) acc[21 + r] += (double)((JtM[r][0] * e[0] + JtM[r][1] * e[1]) + JtM[r][2] * e[2]);
