@@ -16,3 +16,18 @@ for tgt in (False, True):
 T = p.guess.astype(np.float64)
 c0, H0, b0 = o.linearize(T); c1, H1, b1, inl = g.evaluate_cost(T)
 print("H rel", np.abs(H1-H0).max()/np.abs(H0).max(), "b rel", np.abs(b1-b0).max()/np.abs(b0).max(), "c rel", abs(c1-c0)/abs(c0), inl, o.num_inliers)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import pose_error
+from oracle.loader import result_T
+print("lower-triangle H diff rel", np.abs(np.tril(H1 - H0)).max() / np.abs(H0).max())
+for opt, nn in (("LM", 1), ("GN", 7), ("GN", 1)):
+    g = pcm.VgicpCudaRegistration(0, optimizer=opt, num_neighbors=nn); cfg = g.config
+    o = Oracle("VGICP_CUDA", opt, voxel_resolution=cfg.voxel_resolution, num_neighbors=nn, k_correspondences=cfg.k_correspondences, regularization=cfg.regularization)
+    o.set_input_target(p.submap); o.set_input_source(p.scan); g.set_input_target(p.submap); g.set_input_source(p.scan)
+    o.enable_trace(256)
+    ro, rg = o.align(p.guess), g.align(p.guess)
+    print(opt, nn, "iters", rg.iterations, ro.iterations, "pose diff", pose_error(result_T(ro), rg.T64), "evals", rg.num_linearize, ro.num_linearize, rg.num_compute_error, ro.num_compute_error)
+    # replay: compare linearize at the oracle's final pose
+    Tf = result_T(ro)
+    c0, H0, b0 = o.linearize(Tf); c1, H1, b1, inl = g.evaluate_cost(Tf)
+    print("   at final pose: tril H rel", np.abs(np.tril(H1 - H0)).max() / np.abs(H0).max(), "b rel", np.abs(b1 - b0).max() / np.abs(b0).max(), "inl", inl, o.num_inliers)
