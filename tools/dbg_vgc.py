@@ -31,3 +31,20 @@ for opt, nn in (("LM", 1), ("GN", 7), ("GN", 1)):
     Tf = result_T(ro)
     c0, H0, b0 = o.linearize(Tf); c1, H1, b1, inl = g.evaluate_cost(Tf)
     print("   at final pose: tril H rel", np.abs(np.tril(H1 - H0)).max() / np.abs(H0).max(), "b rel", np.abs(b1 - b0).max() / np.abs(b0).max(), "inl", inl, o.num_inliers)
+print("---- trial cost")
+g = pcm.VgicpCudaRegistration(0, optimizer="LM", num_neighbors=1); cfg = g.config
+o = Oracle("VGICP_CUDA", "LM", voxel_resolution=cfg.voxel_resolution, num_neighbors=1, k_correspondences=cfg.k_correspondences, regularization=cfg.regularization, max_iterations=1)
+o.set_input_target(p.submap); o.set_input_source(p.scan); g.set_input_target(p.submap); g.set_input_source(p.scan)
+T = p.guess.astype(np.float64)
+c0, H0, b0 = o.linearize(T); c1, H1, b1, inl = g.evaluate_cost(T)
+for d in ([0.02, -0.01, 0.01], [0.001, 0.0, 0.0], [0.2, 0.1, -0.1]):
+    T2 = T.copy(); T2[:3, 3] += d
+    e0, e1 = o.compute_error(T2), g.compute_error(T2)
+    print(d, e0, e1, abs(e1 - e0) / abs(e0))
+o.enable_trace(64)
+ro = o.align(p.guess)
+print("oracle trace", o.trace()[:6] if hasattr(o, "trace") else None)
+g2 = pcm.VgicpCudaRegistration(0, optimizer="LM", num_neighbors=1, max_iterations=1); g2.set_input_target(p.submap); g2.set_input_source(p.scan)
+rg = g2.align(p.guess)
+print("gpu", rg.num_linearize, rg.num_compute_error, rg.cost, "oracle", ro.num_linearize, ro.num_compute_error, ro.cost)
+print(np.abs(rg.T64 - result_T(ro)).max())
