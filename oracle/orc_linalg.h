@@ -97,6 +97,9 @@ static inline void orc_ldlt6_solve(const double A_in[36], const double rhs[6], d
   double A[36];
   int perm[6];
   memcpy(A, A_in, sizeof(A));
+  /* Eigen's LDLT<.., Lower> reads the lower triangle only; the steps below move entries symmetrically, so start from the
+   * self-adjoint completion of the lower triangle (matters for the float models, whose summed H is not exactly symmetric) */
+  for (int i = 0; i < 6; i++) for (int j = i + 1; j < 6; j++) A[i * 6 + j] = A[j * 6 + i];
   for (int i = 0; i < 6; i++) perm[i] = i;
   /* in-place lower LDLT with symmetric pivoting (only the lower triangle is read) */
   for (int k = 0; k < 6; k++) {
