@@ -172,3 +172,14 @@ def test_cuda_align_matches_oracle(pcm, pair, optimizer, kw):
         dt, dr = pose_error(result_T(ro), rg.T64)
         assert dt < 1e-9 and dr < 1e-9, (iters, dt, dr)
         assert rg.num_linearize == ro.num_linearize and rg.num_compute_error == ro.num_compute_error
+
+
+def test_cuda_full_align_on_a_dense_pair(pcm, synth):
+    from oracle.loader import result_T
+    p = synth.make_pair(0, 10000, 100000, density=60.0)
+    for optimizer, nn in (("LM", 1), ("GN", 7)):
+        o, g = _both_cuda(pcm, optimizer, p, num_neighbors=nn)
+        ro, rg = o.align(p.guess), g.align(p.guess)
+        dt, dr = pose_error(result_T(ro), rg.T64)
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (optimizer, nn, dt, dr)
+        assert rg.iterations == ro.iterations and rg.converged == bool(ro.converged)
