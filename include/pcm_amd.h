@@ -248,7 +248,7 @@ int pcm_align_batch(pcm_ctx *const *ctxs, int n, const float *guesses, pcm_resul
  * probe counters (slower kernel variant; use in an untimed pass); bit2 = in-kernel
  * phase stamps of the correspondence-search kernel (diagnostic build) */
 int pcm_set_profiling(pcm_ctx *ctx, int flags);
-/* diagnostic (profiling bit2): per-phase s_memtime sums of k_corr_search, [7] = tiles; resets on read */
+/* diagnostic (profiling bit2): per-phase s_memtime sums of k_linearize, [7] = tiles; resets on read */
 int pcm_debug_phase_cycles(pcm_ctx *ctx, uint64_t out[8]);
 int pcm_get_stats(pcm_ctx *ctx, pcm_stats *out);
 int pcm_reset_stats(pcm_ctx *ctx);

@@ -1,10 +1,12 @@
-// kernels.hip -- the per-round kernels of the scan-to-submap registration path (gfx950):
+// kernels.hip -- the per-round kernels of the point-to-plane scan-to-submap path (gfx950):
 //
-//   k_corr_search      correspondence search: 5-NN of every scan point in the
-//                      linear-probed voxel hash of the submap + plane fit
-//   k_residual_reduce  point-to-plane residual / Jacobian + 6x6 normal-equation
-//                      accumulation (wave64 reduction, deterministic partials)
-//   k_lsq_step         fixed-order sum of the partials + GN / LM state machine
+//   k_linearize      one launch per GN / LM round: 5-NN of every scan point in the brick voxel hash of the
+//                    submap, plane fit, point-to-plane residual / Jacobian and the 29 normal-equation sums
+//                    of the tile (one partial row per 256-point workgroup); LIO variant: the 12-column IEKF
+//                    measurement row and its 92 sums
+//   k_finish_round   fixed-order sum of the partial rows + the GN / LM state machine (lsq_step.h), one
+//                    status byte per pair into mapped host memory
+//   k_trial          LM trial cost on the planes of the last linearize
 //
 // Replaces, for the MI355X path (paths relative to /root/reference/src):
 //   - LaserMapping::ObsModel matcher loop            jueying_lio/src/laser_mapping.cc:606-637
@@ -16,19 +18,16 @@
 //                                                    pointcloud_match/fast_gicp/src/fast_gicp/cuda/{find_voxel_correspondences,compute_derivatives}.cu
 //   - LsqRegistration step_gn / step_lm              pointcloud_match/fast_gicp/include/fast_gicp/gicp/impl/lsq_registration_impl.hpp:105-172
 //
-// Shape (not a port).  The scan is ordered along a Morton curve once per scan,
-// so the 256 points of a workgroup tile sit in a few neighbouring voxels.  The
-// tile's voxel bounding box (+1 halo) is resolved against the global hash ONCE
-// per tile -- one probe per cell instead of 27 per point -- into a dense LDS
-// grid, and the map points of those cells are staged through LDS with coalesced
-// 16-byte loads; each lane then runs its 27-cell / 5-NN search and the plane fit
-// entirely out of LDS and registers.  Tiles whose box does not fit fall back to
-// per-lane probing of the global table with the first probes of 9 cells in
-// flight at once.  No correspondence list is written to HBM: the only per-point
-// output is the fitted plane (one float4), which the second kernel turns into
-// the 28 unique normal-equation terms (float geometry, double accumulation,
-// wave64 cross-lane reduction, one partial row per workgroup).  The GN/LM state
-// stays on the device for the whole align().
+// Shape (not a port).  The scan is ordered along a Morton curve once per scan, so the 256 points of a
+// workgroup tile sit in a few neighbouring voxels.  The tile's voxel bounding box (+1 halo) is resolved
+// against the brick hash ONCE per tile -- one probe per 8x8x8-voxel brick -- and the bricks' map points are
+// staged through LDS with coalesced 16-byte loads; every voxel head registers itself in a dense LDS cell
+// grid; each lane then runs its 27-cell / 5-NN search and the plane fit out of LDS and registers.  Tiles
+// whose box does not fit fall back to per-lane probing of the global structures.  No correspondence list
+// is written to HBM; the residual row goes through LDS into the tile's sums (float geometry, double
+// accumulation, fixed order).  The GN / LM state stays on the device for the whole align().
+// The kernel is VALU-bound: 2 463 vector instructions per wave, 1 672 of them in the
+// search loop, which a wave executes for the union of its lanes' needs.
 //
 // Compiled with -ffp-contract=off: the float geometry that feeds discrete
 // decisions (voxel key, kNN order, plane test) must round like the reference's
@@ -265,7 +264,7 @@ void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState*
 }
 
 // ---------------------------------------------------------------------------
-// k_corr_search: grid = (tiles_per_pair, npairs), block = 256, one scan point per lane
+// k_linearize: grid = (tiles_per_pair, pairs launched), block = 256, one scan point per lane
 // ---------------------------------------------------------------------------
 constexpr int kCapCells = 2048;   // LDS voxel grid of a tile (one uint16 per cell)
 constexpr int kCapPts = 1792;     // map points staged per tile (float4 each); keeps the workgroup under 40 KB of LDS (4 per CU)

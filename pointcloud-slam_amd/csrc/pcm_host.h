@@ -79,7 +79,7 @@ int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, c
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
                          SortScratch* ws, std::string* err);
 
-// residual-kernel launchers (p2plane.hip)
+// residual-kernel launchers (kernels.hip, ndt.hip, gicp.hip)
 struct LaunchGeom {
   int npairs;
   int blocks_per_pair;

@@ -360,7 +360,7 @@ done:
 
 // Re-order the scans of a whole batch along a Morton (Z-order) curve of their WORLD
 // voxel coordinates at the initial guess, so that the 256 points of a
-// k_corr_search tile fall into a few neighbouring voxels of the submap grid
+// k_linearize tile fall into a few neighbouring voxels of the submap grid
 // (their voxel box then fits the LDS grid).  One key kernel + one radix sort +
 // one gather for all pairs of the batch.  Speed only: the normal equations are a
 // sum over points, so the order never changes a result beyond floating-point
