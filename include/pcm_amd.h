@@ -236,6 +236,19 @@ int pcm_ndt_score(pcm_ctx *ctx, const float T[16], double *score);
  * (fast_gicp/include/fast_gicp/gicp/fast_gicp.hpp:64-70; computed at impl/fast_gicp_impl.hpp:239-298). */
 int pcm_get_covariances(pcm_ctx *ctx, int target, double *out, size_t capacity_points, size_t *n);
 
+/* common::Pose6D (jueying_lio/msg/Pose6D.msg): one propagated IMU pose of the frame (rot row-major) */
+typedef struct pcm_imu_pose {
+  double offset_time;   /* seconds after the first lidar point */
+  double acc[3], gyr[3], vel[3], pos[3], rot[9];
+} pcm_imu_pose;
+
+/* Motion compensation of a scan into its frame-end pose, in place (x, y, z of every record are rewritten).
+ * Replaces the backward-propagation loop of ImuProcess::UndistortPcl (jueying_lio/include/imu_processing.hpp:245-285).
+ * `time_offset_bytes`: where the float time stamp of a point [ms] sits in its record (PointXYZINormal::curvature = 40);
+ * points sorted by time (imu_processing.hpp:177-178); `poses`: IMUpose_ (host memory), `end_state`: the propagated state. */
+int pcm_undistort(pcm_ctx *ctx, void *points, size_t n, size_t stride_bytes, size_t time_offset_bytes, int memory, const pcm_imu_pose *poses, int num_poses,
+                  const pcm_lio_state *end_state);
+
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel
  * launches, no host round trip per iteration.  `guesses` = n x 16 floats.

@@ -242,5 +242,19 @@ class Oracle:
         return res
 
 
+def undistort(points, time_index, poses, rot_xyzw, pos, off_R_xyzw, off_T):
+    """orc_undistort on an (N,F) float32 array, in place (poses: (K,22) float64 Pose6D rows)."""
+    L = lib()
+    assert points.dtype == np.float32 and points.flags["C_CONTIGUOUS"]
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    st = LioState()
+    st.rot[:] = list(map(float, rot_xyzw)); st.pos[:] = list(map(float, pos))
+    st.off_R[:] = list(map(float, off_R_xyzw)); st.off_T[:] = list(map(float, off_T))
+    L.orc_undistort.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_int, C.POINTER(LioState)]
+    L.orc_undistort.restype = None
+    L.orc_undistort(points.ctypes.data, points.shape[0], points.shape[1], int(time_index), poses.ctypes.data, poses.shape[0], C.byref(st))
+    return points
+
+
 def result_T(res) -> np.ndarray:
     return np.array(res.T64[:], dtype=np.float64).reshape(4, 4)

@@ -86,6 +86,11 @@ typedef struct orc_lio_state {
   double off_R[4];   /* s.offset_R_L_I   imu <- lidar */
   double off_T[3];   /* s.offset_T_L_I */
 } orc_lio_state;
+/* common::Pose6D (jueying_lio/msg/Pose6D.msg): one IMU pose of the frame */
+typedef struct orc_imu_pose { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; } orc_imu_pose;
+/* ImuProcess::UndistortPcl backward propagation (imu_processing.hpp:245-285), in place; the time of a point (ms, float) is
+ * the float at index time_index of its record (PointXYZINormal::curvature) */
+void orc_undistort(float *pts, long n, long stride_floats, long time_index, const orc_imu_pose *poses, int npose, const orc_lio_state *st);
 /* LaserMapping::ObsModel (jueying_lio/src/laser_mapping.cc:592-701) + the reduction the IEKF
  * applies to it, HTH = h_x^T h_x and h_x^T h (esekfom.hpp:1687,1706).  converge != 0: re-match
  * (5-NN + plane fit); converge == 0: re-use the planes of the previous call.  Returns 0, or -1

@@ -847,6 +847,36 @@ int pcm_ndt_score(pcm_ctx* c, const float T[16], double* score) {
   return PCM_OK;
 }
 
+// ImuProcess::UndistortPcl backward propagation  (jueying_lio/include/imu_processing.hpp:245-285)
+int pcm_undistort(pcm_ctx* c, void* points, size_t n, size_t stride, size_t time_off, int memory, const pcm_imu_pose* poses, int npose, const pcm_lio_state* st) {
+  CHECK_CTX(c);
+  if ((!points && n) || !poses || !st || npose < 0) return PCM_ERR_INVALID_ARGUMENT;
+  if (stride < 16 || (stride % 4) != 0 || time_off + 4 > stride || (time_off % 4) != 0) { c->err = "bad record layout"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (n == 0 || npose < 2) return PCM_OK;
+  HIPCK(c, hipSetDevice(c->device));
+  pcm_imu_pose* d_poses = nullptr;
+  char* d_tmp = nullptr;
+  int rc = PCM_OK;
+  LioStateD s;
+  for (int a = 0; a < 4; a++) { s.rot[a] = st->rot[a]; s.off_R[a] = st->off_R[a]; }
+  for (int a = 0; a < 3; a++) { s.pos[a] = st->pos[a]; s.off_T[a] = st->off_T[a]; }
+  if (hipMalloc(&d_poses, sizeof(pcm_imu_pose) * (size_t)npose) != hipSuccess) { c->err = "hipMalloc failed"; return PCM_ERR_HIP; }
+  hipError_t e = hipMemcpyAsync(d_poses, poses, sizeof(pcm_imu_pose) * (size_t)npose, hipMemcpyHostToDevice, c->stream);
+  void* d_pts = points;
+  if (e == hipSuccess && memory == PCM_MEM_HOST) {
+    e = hipMalloc(&d_tmp, n * stride);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tmp, points, n * stride, hipMemcpyHostToDevice, c->stream);
+    d_pts = d_tmp;
+  }
+  if (e == hipSuccess) rc = undistort_device(c->stream, d_pts, n, stride, time_off, d_poses, npose, s, &c->err);
+  if (e == hipSuccess && rc == PCM_OK && memory == PCM_MEM_HOST) e = hipMemcpyAsync(points, d_tmp, n * stride, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_poses);
+  if (d_tmp) hipFree(d_tmp);
+  if (e != hipSuccess) { c->err = std::string("pcm_undistort: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return rc;
+}
+
 // getSourceCovariances / getTargetCovariances  fast_gicp.hpp:64-70  (input order, row-major 3x3 blocks)
 int pcm_get_covariances(pcm_ctx* c, int target, double* out, size_t capacity_points, size_t* n) {
   CHECK_CTX(c);

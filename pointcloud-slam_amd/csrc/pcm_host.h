@@ -76,6 +76,8 @@ struct SortScratch {
 struct LioStateD { double rot[4], pos[3], off_R[4], off_T[3]; };
 int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, const LioStateD& s, float filter_size_map, const uint32_t* nn, const float4* map_pts,
                            uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err);
+// preprocess.hip
+int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride, size_t time_off, const pcm_imu_pose* d_poses, int npose, const LioStateD& s, std::string* err);
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
                          SortScratch* ws, std::string* err);
 

@@ -205,6 +205,20 @@ class Registration:
     def set_correspondence_randomness(self, k): self._set(k_correspondences=int(k))   # setCorrespondenceRandomness  fast_gicp_impl.hpp:61-63
     def set_regularization_method(self, m): self._set(regularization=m)               # setRegularizationMethod      :66-68
 
+    def undistort(self, points, time_index, poses, rot_xyzw, pos, off_R_xyzw, off_T):
+        """Motion compensation of a scan into its frame-end pose, in place (ImuProcess::UndistortPcl's backward propagation,
+        jueying_lio/include/imu_processing.hpp:245-285).  points: (N,F) float32 (x,y,z first, time [ms] in column time_index,
+        sorted by time); poses: (K,22) float64 rows = Pose6D (offset_time, acc, gyr, vel, pos, rot row-major)."""
+        assert points.dtype == np.float32 and points.flags["C_CONTIGUOUS"] and points.ndim == 2
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        assert poses.ndim == 2 and poses.shape[1] == 22
+        st = capi.PcmLioState()
+        st.rot[:] = list(map(float, rot_xyzw)); st.pos[:] = list(map(float, pos))
+        st.off_R[:] = list(map(float, off_R_xyzw)); st.off_T[:] = list(map(float, off_T))
+        self._check(self._L.pcm_undistort(self._h, points.ctypes.data, points.shape[0], points.strides[0], 4 * int(time_index), capi.MEM_HOST,
+                                          poses.ctypes.data, poses.shape[0], C.byref(st)))
+        return points
+
     def get_target(self) -> np.ndarray:
         """(M,3) current target points in insertion order."""
         n = C.c_size_t()

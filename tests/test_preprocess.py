@@ -1,0 +1,69 @@
+"""Scan pre-processing: IMU motion compensation of a scan."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+
+def _frame(n=6000, first_ms=7.0, seed=0):
+    """A 100 ms frame: 11 propagated IMU poses (every 10 ms, mildly accelerating turn), points sorted by time.  The first
+    point is sampled after the first IMU poses, which triggers the reference loop's repeated visit of that point."""
+    rng = np.random.default_rng(seed)
+    K = 11
+    poses = np.zeros((K, 22))
+    acc = np.array([0.3, -0.2, 0.11]); gyr = np.array([0.2, -0.3, 0.6]); dt = 0.01
+    R = Rotation.from_euler("xyz", [0.02, -0.01, 0.3]); vel = np.array([5.0, 0.5, -0.1]); pos = np.zeros(3)
+    for k in range(K):                                       # a self-consistent propagation: constant body rate and acceleration
+        poses[k, 0] = dt * k
+        poses[k, 1:4] = acc; poses[k, 4:7] = gyr; poses[k, 7:10] = vel; poses[k, 10:13] = pos
+        poses[k, 13:22] = R.as_matrix().ravel()
+        pos = pos + vel * dt + 0.5 * acc * dt * dt
+        vel = vel + acc * dt
+        R = R * Rotation.from_rotvec(gyr * dt)
+    pts = np.zeros((n, 12), np.float32)                     # PointXYZINormal: 48 bytes, curvature = column 10
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pts[:, :3] = (d * rng.uniform(2.0, 60.0, (n, 1))).astype(np.float32)
+    times = np.sort(rng.uniform(first_ms, 100.0, n)).astype(np.float32)
+    times[0] = first_ms
+    times[50] = 30.0                                         # exactly on an IMU stamp: belongs to the segment before it
+    pts[:, 10] = np.sort(times)
+    rot_end = Rotation.from_matrix(poses[-1, 13:22].reshape(3, 3)).as_quat()
+    state = dict(rot_xyzw=rot_end, pos=poses[-1, 10:13], off_R_xyzw=Rotation.from_euler("xyz", [0.01, -0.02, 0.03]).as_quat(), off_T=[0.05, -0.02, 0.1])
+    return pts, poses, state
+
+
+def test_undistort_oracle_properties():
+    """orc_preprocess.c: a point sampled at the frame end with the end pose is unchanged; with zero motion nothing moves;
+    the first point takes the extra visits the reference loop gives it."""
+    from oracle.loader import undistort
+    pts, poses, st = _frame()
+    still = poses.copy(); still[:, 1:13] = 0.0; still[:, 13:22] = np.eye(3).ravel()
+    st0 = dict(rot_xyzw=[0, 0, 0, 1], pos=[0, 0, 0], off_R_xyzw=st["off_R_xyzw"], off_T=st["off_T"])
+    a = pts.copy(); undistort(a, 10, still, **st0)
+    assert np.abs(a[:, :3] - pts[:, :3]).max() < 2e-5        # zero motion: only double -> float rounding of the round trip
+    b = pts.copy(); undistort(b, 10, poses, **st)
+    moved = np.linalg.norm(b[:, :3] - pts[:, :3], axis=1)
+    assert moved[-1] < 1e-3 and moved[1] > 0.1               # a point sampled at the frame end stays, an early one moves by the ego-motion
+    assert np.array_equal(b[:, 3:], pts[:, 3:])              # only x, y, z are rewritten
+    # the first point is visited once per segment below its own (here: 7 ms -> segments starting at 0 ms only: one visit)
+    c = pts.copy(); c[0, 10] = 35.0; c[1:, 10] = np.maximum(c[1:, 10], 35.0)
+    ref = c.copy(); undistort(ref, 10, poses, **st)
+    dummy = np.zeros((1, 12), np.float32); dummy[0, :3] = 1.0; dummy[0, 10] = 34.9       # another point in front: c[0] becomes ordinary
+    single = np.ascontiguousarray(np.vstack([dummy, c]))
+    undistort(single, 10, poses, **st)
+    assert not np.allclose(single[1, :3], ref[0, :3], atol=1e-4)      # as an ordinary point it gets ONE compensation, as first point four
+    assert np.array_equal(single[2:, :3], ref[1:, :3])
+
+
+@pytest.mark.gpu
+def test_undistort_matches_oracle(pcm):
+    from oracle.loader import undistort
+    for first_ms, seed in ((7.0, 0), (35.0, 1), (0.0, 2)):
+        pts, poses, st = _frame(first_ms=first_ms, seed=seed)
+        a, b = pts.copy(), pts.copy()
+        undistort(a, 10, poses, **st)
+        reg = pcm.P2PlaneRegistration(0)
+        reg.undistort(b, 10, poses, **st)
+        assert np.array_equal(a[:, 3:], b[:, 3:])
+        ulp = np.spacing(np.maximum(np.abs(a[:, :3]), 1.0).astype(np.float32))
+        assert (np.abs(a[:, :3] - b[:, :3]) <= 2 * ulp).all()          # device sin/cos vs libm: at most the last float bit or two
+        assert (a[:, :3] == b[:, :3]).mean() > 0.99
