@@ -228,9 +228,13 @@ int prepare(pcm_ctx* c) {
       c->src_cov_valid = false; c->tgt_cov_valid = false;
       c->cov_k = c->cfg.k_correspondences; c->cov_reg = c->cfg.regularization + 100 * c->cfg.model; c->cov_vmode = c->cfg.voxel_mode;
     }
-    if (!c->srcmap.valid || c->srcmap.res != c->cfg.voxel_resolution || c->srcmap.coord_mode != mode) {
+    // the scan's own grid is only the index of its kNN search: a finer cell keeps the candidate lists short where a
+    // LiDAR scan is dense (near the sensor one 0.5 m voxel holds thousands of points)
+    static const float src_factor = [] { const char* e = getenv("PCM_SRC_GRID_FACTOR"); return e ? (float)atof(e) : 1.0f; }();
+    const float src_res = c->cfg.voxel_resolution * src_factor;
+    if (!c->srcmap.valid || c->srcmap.res != src_res || c->srcmap.coord_mode != mode) {
       uint32_t n_src = (uint32_t)c->src.n;
-      int rc = build_target_map(c->stream, c->src.d_pts, &n_src, c->cfg.voxel_resolution, mode, false, 0u, &c->srcmap, &c->err, true);
+      int rc = build_target_map(c->stream, c->src.d_pts, &n_src, src_res, mode, false, 0u, &c->srcmap, &c->err, true);
       if (rc != PCM_OK) return rc;
       c->src_cov_valid = false;
     }
