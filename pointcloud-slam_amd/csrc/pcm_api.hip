@@ -230,8 +230,8 @@ int prepare(pcm_ctx* c) {
     }
     // the scan's own grid is only the index of its kNN search: a finer cell keeps the candidate lists short where a
     // LiDAR scan is dense (near the sensor one 0.5 m voxel holds thousands of points)
-    static const float src_factor = [] { const char* e = getenv("PCM_SRC_GRID_FACTOR"); return e ? (float)atof(e) : 1.0f; }();
-    const float src_res = c->cfg.voxel_resolution * src_factor;
+    // (measured on Livox-shaped 100 k-point scans: 0.5 m cells are the optimum; 1.0 m costs 25 %, 0.25 m 15-40 %)
+    const float src_res = std::min(c->cfg.voxel_resolution, 0.5f);
     if (!c->srcmap.valid || c->srcmap.res != src_res || c->srcmap.coord_mode != mode) {
       uint32_t n_src = (uint32_t)c->src.n;
       int rc = build_target_map(c->stream, c->src.d_pts, &n_src, src_res, mode, false, 0u, &c->srcmap, &c->err, true);
