@@ -282,8 +282,8 @@ def main():
                          "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]),
                          "residual_kernel_avg_ms": st["residual_ms"] / launches},
         }
-        if args.cpu_seconds > 0 and world >= 1:
-            out["cpu_baseline"] = cpu_baseline(pairs, cfg, args.cpu_seconds)
+        # the CPU leg is timed on rank 0 of the single-GPU run only (the other ranks would idle behind it)
+        out["cpu_baseline"] = cpu_baseline(pairs, cfg, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
