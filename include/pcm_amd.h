@@ -249,6 +249,11 @@ typedef struct pcm_imu_pose {
 int pcm_undistort(pcm_ctx *ctx, void *points, size_t n, size_t stride_bytes, size_t time_offset_bytes, int memory, const pcm_imu_pose *poses, int num_poses,
                   const pcm_lio_state *end_state);
 
+/* pcl::VoxelGrid down-sampling of a scan: one centroid per occupied leaf, in increasing leaf-index order, every float
+ * field of the record averaged (records of 3..16 floats, x y z first).  `out` must hold n records; *n_out = cells.
+ * Replaces voxel_scan_.filter() of LaserMapping::Run (jueying_lio/src/laser_mapping.cc:323-328). */
+int pcm_voxel_downsample(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory, float leaf_size, void *out, size_t capacity_points, size_t *n_out);
+
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel
  * launches, no host round trip per iteration.  `guesses` = n x 16 floats.

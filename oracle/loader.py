@@ -256,5 +256,18 @@ def undistort(points, time_index, poses, rot_xyzw, pos, off_R_xyzw, off_T):
     return points
 
 
+def voxel_downsample(points, leaf):
+    """orc_voxel_downsample on an (N,F) float32 array -> (M,F) float32."""
+    L = lib()
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    out = np.zeros_like(points)
+    L.orc_voxel_downsample.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_float, C.c_void_p]
+    L.orc_voxel_downsample.restype = C.c_long
+    m = L.orc_voxel_downsample(points.ctypes.data, points.shape[0], points.shape[1], float(leaf), out.ctypes.data)
+    if m < 0:
+        raise OverflowError("leaf size too small for the extent of the cloud")
+    return out[:m].copy()
+
+
 def result_T(res) -> np.ndarray:
     return np.array(res.T64[:], dtype=np.float64).reshape(4, 4)

@@ -59,3 +59,62 @@ void orc_undistort(float *pts, long n, long stride_floats, long time_index, cons
     }
   }
 }
+
+/*
+ * pcl::VoxelGrid<PointT>::applyFilter as LaserMapping::Run uses it (jueying_lio/src/laser_mapping.cc:323-328; PCL is not
+ * in the tree: restated from pcl/filters/impl/voxel_grid.hpp): bounding box of the finite points, cell of a point =
+ * floor(p * inverse_leaf_size) - min_b, linear index ijk . (1, dx, dx dy), one output point per occupied cell in increasing
+ * index order, every float field of the record averaged (downsample_all_data_).  PCL sums the fields in float in the order
+ * std::sort happens to leave equal indices; here the sums are double in input order, cast to float.
+ * Returns the number of output points, or -1 when the index would overflow int32 (PCL warns and returns the input's size 0).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+
+typedef struct { int64_t idx; long cp; } orc_vg_item;
+static int vg_cmp(const void *a, const void *b) {
+  const orc_vg_item *x = (const orc_vg_item *)a, *y = (const orc_vg_item *)b;
+  if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+  return x->cp < y->cp ? -1 : (x->cp > y->cp ? 1 : 0);
+}
+
+long orc_voxel_downsample(const float *pts, long n, long stride_floats, float leaf, float *out) {
+  const float inv = 1.0f / leaf;
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  long nf = 0;
+  for (long i = 0; i < n; i++) {
+    const float *p = pts + i * stride_floats;
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    nf++;
+    for (int a = 0; a < 3; a++) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+  }
+  if (nf == 0) return 0;
+  const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > (int64_t)INT32_MAX) return -1;
+  int min_b[3], max_b[3];
+  for (int a = 0; a < 3; a++) { min_b[a] = (int)floorf(mn[a] * inv); max_b[a] = (int)floorf(mx[a] * inv); }
+  const int64_t div0 = max_b[0] - min_b[0] + 1, div1 = max_b[1] - min_b[1] + 1;
+  orc_vg_item *it = (orc_vg_item *)malloc(sizeof(orc_vg_item) * (size_t)nf);
+  long m = 0;
+  for (long i = 0; i < n; i++) {
+    const float *p = pts + i * stride_floats;
+    if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+    const int64_t i0 = (int64_t)(floorf(p[0] * inv) - (float)min_b[0]), i1 = (int64_t)(floorf(p[1] * inv) - (float)min_b[1]), i2 = (int64_t)(floorf(p[2] * inv) - (float)min_b[2]);
+    it[m].idx = i0 + i1 * div0 + i2 * div0 * div1;
+    it[m].cp = i;
+    m++;
+  }
+  qsort(it, (size_t)m, sizeof(orc_vg_item), vg_cmp);
+  long nout = 0;
+  double *acc = (double *)malloc(sizeof(double) * (size_t)stride_floats);
+  for (long s = 0; s < m;) {
+    long e = s;
+    for (long f = 0; f < stride_floats; f++) acc[f] = 0.0;
+    while (e < m && it[e].idx == it[s].idx) { for (long f = 0; f < stride_floats; f++) acc[f] += (double)pts[it[e].cp * stride_floats + f]; e++; }
+    for (long f = 0; f < stride_floats; f++) out[nout * stride_floats + f] = (float)(acc[f] / (double)(e - s));
+    nout++;
+    s = e;
+  }
+  free(acc); free(it);
+  return nout;
+}

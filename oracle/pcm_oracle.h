@@ -91,6 +91,8 @@ typedef struct orc_imu_pose { double offset_time, acc[3], gyr[3], vel[3], pos[3]
 /* ImuProcess::UndistortPcl backward propagation (imu_processing.hpp:245-285), in place; the time of a point (ms, float) is
  * the float at index time_index of its record (PointXYZINormal::curvature) */
 void orc_undistort(float *pts, long n, long stride_floats, long time_index, const orc_imu_pose *poses, int npose, const orc_lio_state *st);
+/* pcl::VoxelGrid down-sampling of a scan (laser_mapping.cc:323-328): out holds up to n records; returns the count, -1 on index overflow */
+long orc_voxel_downsample(const float *pts, long n, long stride_floats, float leaf, float *out);
 /* LaserMapping::ObsModel (jueying_lio/src/laser_mapping.cc:592-701) + the reduction the IEKF
  * applies to it, HTH = h_x^T h_x and h_x^T h (esekfom.hpp:1687,1706).  converge != 0: re-match
  * (5-NN + plane fit); converge == 0: re-use the planes of the previous call.  Returns 0, or -1

@@ -881,6 +881,33 @@ int pcm_undistort(pcm_ctx* c, void* points, size_t n, size_t stride, size_t time
   return rc;
 }
 
+// pcl::VoxelGrid::filter of the scan (jueying_lio/src/laser_mapping.cc:323-328)
+int pcm_voxel_downsample(pcm_ctx* c, const void* points, size_t n, size_t stride, int memory, float leaf, void* out, size_t capacity_points, size_t* n_out) {
+  CHECK_CTX(c);
+  if ((!points && n) || !out || !n_out) return PCM_ERR_INVALID_ARGUMENT;
+  if (capacity_points < n) { c->err = "the output buffer must hold as many records as the input"; return PCM_ERR_INVALID_ARGUMENT; }
+  *n_out = 0;
+  if (n == 0) return PCM_OK;
+  HIPCK(c, hipSetDevice(c->device));
+  char *d_in = nullptr, *d_out = nullptr;
+  const void* src = points;
+  void* dst = out;
+  hipError_t e = hipSuccess;
+  if (memory == PCM_MEM_HOST) {
+    e = hipMalloc(&d_in, n * stride);
+    if (e == hipSuccess) e = hipMalloc(&d_out, n * stride);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, points, n * stride, hipMemcpyHostToDevice, c->stream);
+    src = d_in; dst = d_out;
+  }
+  int rc = PCM_OK;
+  if (e == hipSuccess) rc = voxel_downsample_device(c->stream, src, n, stride, leaf, static_cast<float*>(dst), n_out, &c->err);
+  if (e == hipSuccess && rc == PCM_OK && memory == PCM_MEM_HOST && *n_out) e = hipMemcpy(out, d_out, *n_out * stride, hipMemcpyDeviceToHost);
+  if (d_in) hipFree(d_in);
+  if (d_out) hipFree(d_out);
+  if (e != hipSuccess) { c->err = std::string("pcm_voxel_downsample: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return rc;
+}
+
 // getSourceCovariances / getTargetCovariances  fast_gicp.hpp:64-70  (input order, row-major 3x3 blocks)
 int pcm_get_covariances(pcm_ctx* c, int target, double* out, size_t capacity_points, size_t* n) {
   CHECK_CTX(c);

@@ -78,6 +78,7 @@ int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, c
                            uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err);
 // preprocess.hip
 int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride, size_t time_off, const pcm_imu_pose* d_poses, int npose, const LioStateD& s, std::string* err);
+int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, std::string* err);
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
                          SortScratch* ws, std::string* err);
 

@@ -11,6 +11,10 @@
 #include "pcm_device.h"
 #include "pcm_host.h"
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 namespace pcm {
 
 namespace {
@@ -96,6 +100,129 @@ int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { *err = std::string("k_undistort: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
   return PCM_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// pcl::VoxelGrid down-sampling of the scan (jueying_lio/src/laser_mapping.cc:323-328; pcl/filters/impl/voxel_grid.hpp):
+// cell = floor(p * inverse_leaf_size) - min_b, linear index ijk . (1, dx, dx dy), one centroid per occupied cell in
+// increasing index order, every float field of the record averaged.  PCL sorts (index, point) pairs with std::sort and
+// sums in float; here: radix sort (stable), one lane per cell, double sums in input order.
+// ---------------------------------------------------------------------------
+namespace {
+
+__device__ inline unsigned int f2ord(float f) { const unsigned int u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }   // order-preserving
+inline float ord2f(unsigned int o) { const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; std::memcpy(&f, &u, 4); return f; }
+
+__global__ void k_vg_minmax(const char* __restrict__ base, size_t stride, uint32_t n, unsigned int* __restrict__ mm /* min xyz, max xyz (ordered ints), count */) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = reinterpret_cast<const float*>(base + (size_t)i * stride);
+  if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) return;
+  for (int a = 0; a < 3; a++) { atomicMin(&mm[a], f2ord(p[a])); atomicMax(&mm[3 + a], f2ord(p[a])); }
+  atomicAdd(&mm[6], 1u);
+}
+
+__global__ void k_vg_keys(const char* __restrict__ base, size_t stride, uint32_t n, float inv, int mb0, int mb1, int mb2, long long div0, long long div01, uint64_t* __restrict__ keys,
+                          uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = reinterpret_cast<const float*>(base + (size_t)i * stride);
+  uint64_t key = 1ull << 32;   // non-finite points sort behind every cell
+  if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])) {
+    const long long i0 = (long long)(floorf(p[0] * inv) - (float)mb0), i1 = (long long)(floorf(p[1] * inv) - (float)mb1), i2 = (long long)(floorf(p[2] * inv) - (float)mb2);
+    key = (uint64_t)(i0 + i1 * div0 + i2 * div01);
+  }
+  keys[i] = key;
+  vals[i] = i;
+}
+
+__global__ void k_vg_heads(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ head) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  head[i] = (k < (1ull << 32) && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+
+__global__ void k_vg_average(const char* __restrict__ base, size_t stride, int nfields, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ head,
+                             const uint32_t* __restrict__ slot, uint32_t n, float* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const uint64_t k = keys[i];
+  double acc[16];
+  for (int f = 0; f < 16; f++) acc[f] = 0.0;
+  uint32_t j = i;
+  for (; j < n && keys[j] == k; j++) {
+    const float* p = reinterpret_cast<const float*>(base + (size_t)vals[j] * stride);
+    for (int f = 0; f < nfields; f++) acc[f] += (double)p[f];
+  }
+  float* o = out + (size_t)slot[i] * nfields;
+  for (int f = 0; f < nfields; f++) o[f] = (float)(acc[f] / (double)(j - i));
+}
+
+}  // namespace
+
+// d_in: n records of `stride` bytes (nfields = stride / 4 floats, x y z first); d_out: room for n records.  *n_out receives the count.
+int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, std::string* err) {
+  *n_out = 0;
+  if (n == 0) return PCM_OK;
+  const int nfields = (int)(stride / 4);
+  if (nfields < 3 || nfields > 16 || (stride % 4) != 0) { *err = "records must be 3..16 floats"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (!(leaf > 0.f)) { *err = "leaf size must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
+  const float inv = 1.0f / leaf;
+  unsigned int* d_mm = nullptr;
+  uint64_t *keys = nullptr, *keys_s = nullptr;
+  uint32_t *vals = nullptr, *vals_s = nullptr, *head = nullptr, *slot = nullptr;
+  void *tmp = nullptr, *tmp2 = nullptr;
+  size_t tmp_bytes = 0, tmp2_bytes = 0;
+  int rc = PCM_OK;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  const char* base = static_cast<const char*>(d_in);
+#define CK(x)                                                                    \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
+  } while (0)
+  {
+    unsigned int h_mm[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
+    CK(hipMalloc(&d_mm, sizeof(h_mm)));
+    CK(hipMemcpyAsync(d_mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, stream));
+    k_vg_minmax<<<nb, 256, 0, stream>>>(base, stride, (uint32_t)n, d_mm);
+    CK(hipMemcpyAsync(h_mm, d_mm, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    if (h_mm[6] == 0) goto done;   // no finite point
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = ord2f(h_mm[a]); mx[a] = ord2f(h_mm[3 + a]); }
+    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > 2147483647ll) { *err = "leaf size too small for the extent of the cloud (index overflow)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
+    int min_b[3], max_b[3];
+    for (int a = 0; a < 3; a++) { min_b[a] = (int)floorf(mn[a] * inv); max_b[a] = (int)floorf(mx[a] * inv); }
+    const long long div0 = (long long)max_b[0] - min_b[0] + 1, div1 = (long long)max_b[1] - min_b[1] + 1;
+    CK(hipMalloc(&keys, sizeof(uint64_t) * n)); CK(hipMalloc(&keys_s, sizeof(uint64_t) * n));
+    CK(hipMalloc(&vals, sizeof(uint32_t) * n)); CK(hipMalloc(&vals_s, sizeof(uint32_t) * n));
+    CK(hipMalloc(&head, sizeof(uint32_t) * n)); CK(hipMalloc(&slot, sizeof(uint32_t) * n));
+    k_vg_keys<<<nb, 256, 0, stream>>>(base, stride, (uint32_t)n, inv, min_b[0], min_b[1], min_b[2], div0, div0 * div1, keys, vals);
+    CK(hipGetLastError());
+    CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, n, 0, 33, stream));
+    CK(hipMalloc(&tmp, tmp_bytes));
+    CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, n, 0, 33, stream));
+    k_vg_heads<<<nb, 256, 0, stream>>>(keys_s, (uint32_t)n, head);
+    CK(hipGetLastError());
+    CK(rocprim::exclusive_scan(nullptr, tmp2_bytes, head, slot, 0u, n, rocprim::plus<uint32_t>(), stream));
+    CK(hipMalloc(&tmp2, tmp2_bytes));
+    CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, head, slot, 0u, n, rocprim::plus<uint32_t>(), stream));
+    k_vg_average<<<nb, 256, 0, stream>>>(base, stride, nfields, keys_s, vals_s, head, slot, (uint32_t)n, d_out);
+    CK(hipGetLastError());
+    uint32_t last[2];
+    CK(hipMemcpyAsync(&last[0], slot + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&last[1], head + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    *n_out = (size_t)last[0] + last[1];
+  }
+done:
+  hipFree(d_mm); hipFree(keys); hipFree(keys_s); hipFree(vals); hipFree(vals_s); hipFree(head); hipFree(slot); hipFree(tmp); hipFree(tmp2);
+  return rc;
+#undef CK
 }
 
 }  // namespace pcm

@@ -219,6 +219,16 @@ class Registration:
                                           poses.ctypes.data, poses.shape[0], C.byref(st)))
         return points
 
+    def voxel_downsample(self, points, leaf_size) -> np.ndarray:
+        """pcl::VoxelGrid down-sampling of an (N,F) float32 scan -> (M,F) centroids in leaf-index order
+        (voxel_scan_.filter(), jueying_lio/src/laser_mapping.cc:323-328)."""
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        out = np.zeros_like(points)
+        m = C.c_size_t()
+        self._check(self._L.pcm_voxel_downsample(self._h, points.ctypes.data, points.shape[0], points.strides[0], capi.MEM_HOST, float(leaf_size),
+                                                 out.ctypes.data, out.shape[0], C.byref(m)))
+        return out[:m.value].copy()
+
     def get_target(self) -> np.ndarray:
         """(M,3) current target points in insertion order."""
         n = C.c_size_t()

@@ -67,3 +67,46 @@ def test_undistort_matches_oracle(pcm):
         ulp = np.spacing(np.maximum(np.abs(a[:, :3]), 1.0).astype(np.float32))
         assert (np.abs(a[:, :3] - b[:, :3]) <= 2 * ulp).all()          # device sin/cos vs libm: at most the last float bit or two
         assert (a[:, :3] == b[:, :3]).mean() > 0.99
+
+
+def _scan_for_downsample(seed=3, n=20000):
+    rng = np.random.default_rng(seed)
+    pts = np.zeros((n, 12), np.float32)
+    pts[:, :3] = rng.normal(0, [8.0, 6.0, 1.5], (n, 3)).astype(np.float32)
+    pts[:, 8] = rng.uniform(0, 255, n).astype(np.float32)          # intensity
+    pts[:, 10] = np.sort(rng.uniform(0, 100, n)).astype(np.float32)   # curvature (time)
+    pts[5, 0] = np.nan                                               # non-finite points are dropped
+    return pts
+
+
+def test_voxel_downsample_oracle():
+    """orc_voxel_downsample: one centroid per occupied leaf, increasing leaf-index order, all fields averaged."""
+    from oracle.loader import voxel_downsample
+    pts = _scan_for_downsample()
+    leaf = 0.5
+    out = voxel_downsample(pts, leaf)
+    ok = np.isfinite(pts[:, :3]).all(axis=1)
+    p = pts[ok]
+    inv = np.float32(1.0) / np.float32(leaf)
+    ijk = np.floor(p[:, :3] * inv).astype(np.int64)
+    ijk -= np.floor(p[:, :3].min(axis=0) * inv).astype(np.int64)
+    div = ijk.max(axis=0) + 1
+    idx = ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]
+    uniq = np.unique(idx)
+    assert len(out) == len(uniq)
+    for j in (0, len(uniq) // 2, len(uniq) - 1):
+        assert np.allclose(out[j], p[idx == uniq[j]].astype(np.float64).mean(axis=0), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_voxel_downsample_matches_oracle(pcm):
+    from oracle.loader import voxel_downsample
+    reg = pcm.P2PlaneRegistration(0)
+    for seed, leaf in ((3, 0.5), (4, 0.2), (5, 1.0)):
+        pts = _scan_for_downsample(seed)
+        a = voxel_downsample(pts, leaf)
+        b = reg.voxel_downsample(pts, leaf)
+        assert a.shape == b.shape and np.array_equal(a, b)        # double sums in input order on both sides: bit-equal
+    with pytest.raises(pcm.PcmError):
+        far = _scan_for_downsample(6); far[0, :3] = 1e7
+        reg.voxel_downsample(far, 0.001)                           # index overflow, as PCL refuses it
