@@ -1,0 +1,59 @@
+"""Edge cases of the newer operators: tiny and degenerate inputs must return (a status or a result), never hang or fault."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _classes(pcm):
+    return [pcm.GicpRegistration, pcm.VgicpRegistration, pcm.VgicpCudaRegistration, pcm.NdtRegistration, pcm.PclNdtRegistration]
+
+
+def test_tiny_clouds_return(pcm):
+    rng = np.random.default_rng(0)
+    tgt = rng.normal(0, 1.0, (7, 3)).astype(np.float32)        # fewer points than k_correspondences, no voxel with 6 points
+    src = tgt[:3] + np.float32(0.01)
+    for cls in _classes(pcm):
+        g = cls(0)
+        g.set_input_target(tgt); g.set_input_source(src)
+        try:
+            r = g.align(np.eye(4, dtype=np.float32))
+            assert np.isfinite(r.T64).all() or not r.converged
+        except pcm.PcmError as e:                                # a status is fine, a hang or a fault is not
+            assert e.args
+
+
+def test_missing_input_is_a_status(pcm):
+    for cls in _classes(pcm):
+        g = cls(0)
+        with pytest.raises(pcm.PcmError):
+            g.align(np.eye(4, dtype=np.float32))
+        g.set_input_target(np.zeros((10, 3), np.float32) + np.arange(10, dtype=np.float32)[:, None])
+        with pytest.raises(pcm.PcmError):
+            g.align(np.eye(4, dtype=np.float32))
+
+
+def test_duplicate_points_and_far_source(pcm):
+    """All target points identical (zero covariance) and a source far outside the map."""
+    tgt = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (200, 1))
+    src = np.tile(np.array([[500.0, -300.0, 40.0]], np.float32), (50, 1)) + np.random.default_rng(1).normal(0, 0.1, (50, 3)).astype(np.float32)
+    for cls in _classes(pcm):
+        g = cls(0, max_iterations=3)
+        g.set_input_target(tgt); g.set_input_source(src)
+        try:
+            g.align(np.eye(4, dtype=np.float32))
+        except pcm.PcmError as e:
+            assert e.args
+
+
+def test_bad_configs_are_rejected(pcm):
+    with pytest.raises(pcm.PcmError):
+        pcm.GicpRegistration(0, k_correspondences=0)
+    with pytest.raises(pcm.PcmError):
+        pcm.VgicpRegistration(0, num_neighbors=19)
+    with pytest.raises(pcm.PcmError):
+        pcm.PclNdtRegistration(0, num_neighbors=19)
+    with pytest.raises(pcm.PcmError):
+        pcm.VgicpRegistration(0, voxel_mode=3)
+    with pytest.raises(pcm.PcmError):
+        pcm.PclNdtRegistration(0, ndt_outlier_ratio=1.5)
