@@ -201,6 +201,7 @@ int prepare(pcm_ctx* c) {
     if (!c->pleaf_valid) {
       if (c->pleaf_cap < c->map.num_voxels) {
         if (c->pleaf) hipFree(c->pleaf);
+    if (c->pre_arena) hipFree(c->pre_arena);
         c->pleaf = nullptr; c->pleaf_cap = 0;
         HIPCK(c, hipMalloc(&c->pleaf, sizeof(PclLeaf) * (size_t)c->map.num_voxels));
         c->pleaf_cap = c->map.num_voxels;
@@ -286,6 +287,7 @@ int prepare(pcm_ctx* c) {
     if (c->maha_cap < ncorr) {
       if (c->maha) hipFree(c->maha);
     if (c->pleaf) hipFree(c->pleaf);
+    if (c->pre_arena) hipFree(c->pre_arena);
     if (c->ndt_partials) hipFree(c->ndt_partials);
     if (c->ndt_out) hipFree(c->ndt_out);
     if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
@@ -747,6 +749,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->cvox) hipFree(c->cvox);
     if (c->maha) hipFree(c->maha);
     if (c->pleaf) hipFree(c->pleaf);
+    if (c->pre_arena) hipFree(c->pre_arena);
     if (c->ndt_partials) hipFree(c->ndt_partials);
     if (c->ndt_out) hipFree(c->ndt_out);
     if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
@@ -858,27 +861,29 @@ int pcm_undistort(pcm_ctx* c, void* points, size_t n, size_t stride, size_t time
   if (stride < 16 || (stride % 4) != 0 || time_off + 4 > stride || (time_off % 4) != 0) { c->err = "bad record layout"; return PCM_ERR_INVALID_ARGUMENT; }
   if (n == 0 || npose < 2) return PCM_OK;
   HIPCK(c, hipSetDevice(c->device));
-  pcm_imu_pose* d_poses = nullptr;
-  char* d_tmp = nullptr;
-  int rc = PCM_OK;
   LioStateD s;
   for (int a = 0; a < 4; a++) { s.rot[a] = st->rot[a]; s.off_R[a] = st->off_R[a]; }
   for (int a = 0; a < 3; a++) { s.pos[a] = st->pos[a]; s.off_T[a] = st->off_T[a]; }
-  if (hipMalloc(&d_poses, sizeof(pcm_imu_pose) * (size_t)npose) != hipSuccess) { c->err = "hipMalloc failed"; return PCM_ERR_HIP; }
-  hipError_t e = hipMemcpyAsync(d_poses, poses, sizeof(pcm_imu_pose) * (size_t)npose, hipMemcpyHostToDevice, c->stream);
-  void* d_pts = points;
-  if (e == hipSuccess && memory == PCM_MEM_HOST) {
-    e = hipMalloc(&d_tmp, n * stride);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tmp, points, n * stride, hipMemcpyHostToDevice, c->stream);
-    d_pts = d_tmp;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t need = up(sizeof(pcm_imu_pose) * (size_t)npose) + (memory == PCM_MEM_HOST ? up(n * stride) : 0);
+  if (c->pre_arena_cap < need) {   // grow-only arena shared with pcm_voxel_downsample
+    if (c->pre_arena) hipFree(c->pre_arena);
+    c->pre_arena = nullptr; c->pre_arena_cap = 0;
+    HIPCK(c, hipMalloc(&c->pre_arena, need + need / 4));
+    c->pre_arena_cap = need + need / 4;
   }
-  if (e == hipSuccess) rc = undistort_device(c->stream, d_pts, n, stride, time_off, d_poses, npose, s, &c->err);
-  if (e == hipSuccess && rc == PCM_OK && memory == PCM_MEM_HOST) e = hipMemcpyAsync(points, d_tmp, n * stride, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d_poses);
-  if (d_tmp) hipFree(d_tmp);
-  if (e != hipSuccess) { c->err = std::string("pcm_undistort: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
-  return rc;
+  pcm_imu_pose* d_poses = reinterpret_cast<pcm_imu_pose*>(c->pre_arena);
+  HIPCK(c, hipMemcpyAsync(d_poses, poses, sizeof(pcm_imu_pose) * (size_t)npose, hipMemcpyHostToDevice, c->stream));
+  void* d_pts = points;
+  if (memory == PCM_MEM_HOST) {
+    d_pts = c->pre_arena + up(sizeof(pcm_imu_pose) * (size_t)npose);
+    HIPCK(c, hipMemcpyAsync(d_pts, points, n * stride, hipMemcpyHostToDevice, c->stream));
+  }
+  const int rc = undistort_device(c->stream, d_pts, n, stride, time_off, d_poses, npose, s, &c->err);
+  if (rc != PCM_OK) return rc;
+  if (memory == PCM_MEM_HOST) HIPCK(c, hipMemcpyAsync(points, d_pts, n * stride, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return PCM_OK;
 }
 
 // pcl::VoxelGrid::filter of the scan (jueying_lio/src/laser_mapping.cc:323-328)
@@ -889,23 +894,32 @@ int pcm_voxel_downsample(pcm_ctx* c, const void* points, size_t n, size_t stride
   *n_out = 0;
   if (n == 0) return PCM_OK;
   HIPCK(c, hipSetDevice(c->device));
-  char *d_in = nullptr, *d_out = nullptr;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t io = memory == PCM_MEM_HOST ? 2 * up(n * stride) : 0;
+  const size_t need = voxel_downsample_scratch_bytes(n) + io;
+  if (c->pre_arena_cap < need) {   // grow-only arena: no allocation per frame in the steady state
+    if (c->pre_arena) hipFree(c->pre_arena);
+    c->pre_arena = nullptr; c->pre_arena_cap = 0;
+    HIPCK(c, hipMalloc(&c->pre_arena, need + need / 4));
+    c->pre_arena_cap = need + need / 4;
+  }
   const void* src = points;
   void* dst = out;
-  hipError_t e = hipSuccess;
+  char* scratch = c->pre_arena;
   if (memory == PCM_MEM_HOST) {
-    e = hipMalloc(&d_in, n * stride);
-    if (e == hipSuccess) e = hipMalloc(&d_out, n * stride);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, points, n * stride, hipMemcpyHostToDevice, c->stream);
+    char* d_in = c->pre_arena;
+    char* d_out = c->pre_arena + up(n * stride);
+    scratch = c->pre_arena + io;
+    HIPCK(c, hipMemcpyAsync(d_in, points, n * stride, hipMemcpyHostToDevice, c->stream));
     src = d_in; dst = d_out;
   }
-  int rc = PCM_OK;
-  if (e == hipSuccess) rc = voxel_downsample_device(c->stream, src, n, stride, leaf, static_cast<float*>(dst), n_out, &c->err);
-  if (e == hipSuccess && rc == PCM_OK && memory == PCM_MEM_HOST && *n_out) e = hipMemcpy(out, d_out, *n_out * stride, hipMemcpyDeviceToHost);
-  if (d_in) hipFree(d_in);
-  if (d_out) hipFree(d_out);
-  if (e != hipSuccess) { c->err = std::string("pcm_voxel_downsample: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
-  return rc;
+  int rc = voxel_downsample_device(c->stream, src, n, stride, leaf, static_cast<float*>(dst), n_out, scratch, &c->err);
+  if (rc != PCM_OK) return rc;
+  if (memory == PCM_MEM_HOST && *n_out) {
+    HIPCK(c, hipMemcpyAsync(out, dst, *n_out * stride, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+  }
+  return PCM_OK;
 }
 
 // getSourceCovariances / getTargetCovariances  fast_gicp.hpp:64-70  (input order, row-major 3x3 blocks)

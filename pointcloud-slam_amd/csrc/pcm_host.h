@@ -78,7 +78,8 @@ int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, c
                            uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err);
 // preprocess.hip
 int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride, size_t time_off, const pcm_imu_pose* d_poses, int npose, const LioStateD& s, std::string* err);
-int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, std::string* err);
+size_t voxel_downsample_scratch_bytes(size_t n);
+int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, void* scratch, std::string* err);
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
                          SortScratch* ws, std::string* err);
 
@@ -155,5 +156,7 @@ struct pcm_ctx {
   uint32_t next_seq = 0;           // next insertion sequence number of the target point log
   bool lio_planes_valid = false;   // planes of the last pcm_obs_model(rematch=1) belong to the current scan
   void* ws = nullptr;   // batch workspace owned by this context (pcm_api.hip)
+  char* pre_arena = nullptr;   // grow-only device scratch of the pre-processing operators
+  size_t pre_arena_cap = 0;
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };

@@ -162,65 +162,76 @@ __global__ void k_vg_average(const char* __restrict__ base, size_t stride, int n
 
 }  // namespace
 
-// d_in: n records of `stride` bytes (nfields = stride / 4 floats, x y z first); d_out: room for n records.  *n_out receives the count.
-int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, std::string* err) {
+// scratch bytes voxel_downsample_device needs for n points (keys, values, flags, rocPRIM temporaries)
+size_t voxel_downsample_scratch_bytes(size_t n) {
+  size_t t1 = 0, t2 = 0;
+  uint64_t* k = nullptr; uint32_t* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, t1, k, k, v, v, n, 0, 33, nullptr);
+  (void)rocprim::exclusive_scan(nullptr, t2, v, v, 0u, n, rocprim::plus<uint32_t>(), nullptr);
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  return up(64) + 2 * up(8 * n) + 4 * up(4 * n) + up(t1) + up(t2);
+}
+
+// d_in: n records of `stride` bytes (nfields = stride / 4 floats, x y z first); d_out: room for n records.  *n_out receives
+// the count.  `scratch`: voxel_downsample_scratch_bytes(n) bytes of device memory owned by the caller (no allocation here).
+int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, void* scratch, std::string* err) {
   *n_out = 0;
   if (n == 0) return PCM_OK;
   const int nfields = (int)(stride / 4);
   if (nfields < 3 || nfields > 16 || (stride % 4) != 0) { *err = "records must be 3..16 floats"; return PCM_ERR_INVALID_ARGUMENT; }
   if (!(leaf > 0.f)) { *err = "leaf size must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
   const float inv = 1.0f / leaf;
-  unsigned int* d_mm = nullptr;
-  uint64_t *keys = nullptr, *keys_s = nullptr;
-  uint32_t *vals = nullptr, *vals_s = nullptr, *head = nullptr, *slot = nullptr;
-  void *tmp = nullptr, *tmp2 = nullptr;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t tmp_bytes = 0, tmp2_bytes = 0;
+  {
+    uint64_t* k = nullptr; uint32_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k, k, v, v, n, 0, 33, stream);
+    (void)rocprim::exclusive_scan(nullptr, tmp2_bytes, v, v, 0u, n, rocprim::plus<uint32_t>(), stream);
+  }
+  char* cur = static_cast<char*>(scratch);
+  unsigned int* d_mm = reinterpret_cast<unsigned int*>(cur); cur += up(64);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(cur); cur += up(8 * n);
+  uint64_t* keys_s = reinterpret_cast<uint64_t*>(cur); cur += up(8 * n);
+  uint32_t* vals = reinterpret_cast<uint32_t*>(cur); cur += up(4 * n);
+  uint32_t* vals_s = reinterpret_cast<uint32_t*>(cur); cur += up(4 * n);
+  uint32_t* head = reinterpret_cast<uint32_t*>(cur); cur += up(4 * n);
+  uint32_t* slot = reinterpret_cast<uint32_t*>(cur); cur += up(4 * n);
+  void* tmp = cur; cur += up(tmp_bytes);
+  void* tmp2 = cur;
   int rc = PCM_OK;
   const unsigned nb = (unsigned)((n + 255) / 256);
   const char* base = static_cast<const char*>(d_in);
 #define CK(x)                                                                    \
   do {                                                                           \
     hipError_t e_ = (x);                                                         \
-    if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
+    if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); return PCM_ERR_HIP; } \
   } while (0)
-  {
-    unsigned int h_mm[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
-    CK(hipMalloc(&d_mm, sizeof(h_mm)));
-    CK(hipMemcpyAsync(d_mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, stream));
-    k_vg_minmax<<<nb, 256, 0, stream>>>(base, stride, (uint32_t)n, d_mm);
-    CK(hipMemcpyAsync(h_mm, d_mm, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
-    CK(hipStreamSynchronize(stream));
-    if (h_mm[6] == 0) goto done;   // no finite point
-    float mn[3], mx[3];
-    for (int a = 0; a < 3; a++) { mn[a] = ord2f(h_mm[a]); mx[a] = ord2f(h_mm[3 + a]); }
-    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
-    if (dx * dy * dz > 2147483647ll) { *err = "leaf size too small for the extent of the cloud (index overflow)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
-    int min_b[3], max_b[3];
-    for (int a = 0; a < 3; a++) { min_b[a] = (int)floorf(mn[a] * inv); max_b[a] = (int)floorf(mx[a] * inv); }
-    const long long div0 = (long long)max_b[0] - min_b[0] + 1, div1 = (long long)max_b[1] - min_b[1] + 1;
-    CK(hipMalloc(&keys, sizeof(uint64_t) * n)); CK(hipMalloc(&keys_s, sizeof(uint64_t) * n));
-    CK(hipMalloc(&vals, sizeof(uint32_t) * n)); CK(hipMalloc(&vals_s, sizeof(uint32_t) * n));
-    CK(hipMalloc(&head, sizeof(uint32_t) * n)); CK(hipMalloc(&slot, sizeof(uint32_t) * n));
-    k_vg_keys<<<nb, 256, 0, stream>>>(base, stride, (uint32_t)n, inv, min_b[0], min_b[1], min_b[2], div0, div0 * div1, keys, vals);
-    CK(hipGetLastError());
-    CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, n, 0, 33, stream));
-    CK(hipMalloc(&tmp, tmp_bytes));
-    CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, n, 0, 33, stream));
-    k_vg_heads<<<nb, 256, 0, stream>>>(keys_s, (uint32_t)n, head);
-    CK(hipGetLastError());
-    CK(rocprim::exclusive_scan(nullptr, tmp2_bytes, head, slot, 0u, n, rocprim::plus<uint32_t>(), stream));
-    CK(hipMalloc(&tmp2, tmp2_bytes));
-    CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, head, slot, 0u, n, rocprim::plus<uint32_t>(), stream));
-    k_vg_average<<<nb, 256, 0, stream>>>(base, stride, nfields, keys_s, vals_s, head, slot, (uint32_t)n, d_out);
-    CK(hipGetLastError());
-    uint32_t last[2];
-    CK(hipMemcpyAsync(&last[0], slot + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    CK(hipMemcpyAsync(&last[1], head + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    CK(hipStreamSynchronize(stream));
-    *n_out = (size_t)last[0] + last[1];
-  }
-done:
-  hipFree(d_mm); hipFree(keys); hipFree(keys_s); hipFree(vals); hipFree(vals_s); hipFree(head); hipFree(slot); hipFree(tmp); hipFree(tmp2);
+  unsigned int h_mm[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
+  CK(hipMemcpyAsync(d_mm, h_mm, sizeof(h_mm), hipMemcpyHostToDevice, stream));
+  k_vg_minmax<<<nb, 256, 0, stream>>>(base, stride, (uint32_t)n, d_mm);
+  CK(hipMemcpyAsync(h_mm, d_mm, sizeof(h_mm), hipMemcpyDeviceToHost, stream));
+  CK(hipStreamSynchronize(stream));
+  if (h_mm[6] == 0) return PCM_OK;   // no finite point
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = ord2f(h_mm[a]); mx[a] = ord2f(h_mm[3 + a]); }
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > 2147483647ll) { *err = "leaf size too small for the extent of the cloud (index overflow)"; return PCM_ERR_OUT_OF_RANGE; }
+  int min_b[3], max_b[3];
+  for (int a = 0; a < 3; a++) { min_b[a] = (int)floorf(mn[a] * inv); max_b[a] = (int)floorf(mx[a] * inv); }
+  const long long div0 = (long long)max_b[0] - min_b[0] + 1, div1 = (long long)max_b[1] - min_b[1] + 1;
+  k_vg_keys<<<nb, 256, 0, stream>>>(base, stride, (uint32_t)n, inv, min_b[0], min_b[1], min_b[2], div0, div0 * div1, keys, vals);
+  CK(hipGetLastError());
+  CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, n, 0, 33, stream));
+  k_vg_heads<<<nb, 256, 0, stream>>>(keys_s, (uint32_t)n, head);
+  CK(hipGetLastError());
+  CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, head, slot, 0u, n, rocprim::plus<uint32_t>(), stream));
+  k_vg_average<<<nb, 256, 0, stream>>>(base, stride, nfields, keys_s, vals_s, head, slot, (uint32_t)n, d_out);
+  CK(hipGetLastError());
+  uint32_t last[2];
+  CK(hipMemcpyAsync(&last[0], slot + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&last[1], head + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  CK(hipStreamSynchronize(stream));
+  *n_out = (size_t)last[0] + last[1];
   return rc;
 #undef CK
 }
