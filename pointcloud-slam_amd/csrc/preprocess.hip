@@ -116,11 +116,22 @@ inline float ord2f(unsigned int o) { const unsigned int u = (o & 0x80000000u) ? 
 
 __global__ void k_vg_minmax(const char* __restrict__ base, size_t stride, uint32_t n, unsigned int* __restrict__ mm /* min xyz, max xyz (ordered ints), count */) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float* p = reinterpret_cast<const float*>(base + (size_t)i * stride);
-  if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) return;
-  for (int a = 0; a < 3; a++) { atomicMin(&mm[a], f2ord(p[a])); atomicMax(&mm[3 + a], f2ord(p[a])); }
-  atomicAdd(&mm[6], 1u);
+  unsigned int lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u}, cnt = 0u;
+  if (i < n) {
+    const float* p = reinterpret_cast<const float*>(base + (size_t)i * stride);
+    if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2])) {
+      for (int a = 0; a < 3; a++) { lo[a] = hi[a] = f2ord(p[a]); }
+      cnt = 1u;
+    }
+  }
+  for (int off = 32; off >= 1; off >>= 1) {   // one atomic per wave, not per point
+    for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], (unsigned int)__shfl_xor((int)lo[a], off, 64)); hi[a] = max(hi[a], (unsigned int)__shfl_xor((int)hi[a], off, 64)); }
+    cnt += (unsigned int)__shfl_xor((int)cnt, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    for (int a = 0; a < 3; a++) { atomicMin(&mm[a], lo[a]); atomicMax(&mm[3 + a], hi[a]); }
+    atomicAdd(&mm[6], cnt);
+  }
 }
 
 __global__ void k_vg_keys(const char* __restrict__ base, size_t stride, uint32_t n, float inv, int mb0, int mb1, int mb2, long long div0, long long div01, uint64_t* __restrict__ keys,
