@@ -107,7 +107,7 @@ int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride
 // pcl::VoxelGrid down-sampling of the scan (jueying_lio/src/laser_mapping.cc:323-328; pcl/filters/impl/voxel_grid.hpp):
 // cell = floor(p * inverse_leaf_size) - min_b, linear index ijk . (1, dx, dx dy), one centroid per occupied cell in
 // increasing index order, every float field of the record averaged.  PCL sorts (index, point) pairs with std::sort and
-// sums in float; here: radix sort (stable), one lane per cell, double sums in input order.
+// sums in float; here: radix sort (stable), one wave per cell, double sums (64 interleaved partial sums + a fixed tree).
 // ---------------------------------------------------------------------------
 namespace {
 
@@ -155,20 +155,30 @@ __global__ void k_vg_heads(const uint64_t* __restrict__ keys, uint32_t n, uint32
   head[i] = (k < (1ull << 32) && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
 }
 
-__global__ void k_vg_average(const char* __restrict__ base, size_t stride, int nfields, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ head,
-                             const uint32_t* __restrict__ slot, uint32_t n, float* __restrict__ out) {
+// position of every cell's first element in the sorted order
+__global__ void k_vg_head_pos(const uint32_t* __restrict__ head, const uint32_t* __restrict__ slot, uint32_t n, uint32_t* __restrict__ pos) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !head[i]) return;
-  const uint64_t k = keys[i];
+  if (i < n && head[i]) pos[slot[i]] = i;
+}
+
+// one wave per cell: lane l sums elements l, l + 64, ... of the cell's run in double, then a fixed shuffle tree
+// (deterministic; a dense leaf near the sensor holds thousands of points, which one lane alone would walk serially)
+__global__ void __launch_bounds__(256) k_vg_average(const char* __restrict__ base, size_t stride, int nfields, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pos,
+                                                    uint32_t ncells, uint32_t nvalid, float* __restrict__ out) {
+  const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (cell >= ncells) return;
+  const uint32_t b = pos[cell], e = cell + 1 < ncells ? pos[cell + 1] : nvalid;
   double acc[16];
   for (int f = 0; f < 16; f++) acc[f] = 0.0;
-  uint32_t j = i;
-  for (; j < n && keys[j] == k; j++) {
+  for (uint32_t j = b + lane; j < e; j += 64) {
     const float* p = reinterpret_cast<const float*>(base + (size_t)vals[j] * stride);
     for (int f = 0; f < nfields; f++) acc[f] += (double)p[f];
   }
-  float* o = out + (size_t)slot[i] * nfields;
-  for (int f = 0; f < nfields; f++) o[f] = (float)(acc[f] / (double)(j - i));
+  for (int f = 0; f < nfields; f++) {
+    double v = acc[f];
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) out[(size_t)cell * nfields + f] = (float)(v / (double)(e - b));
+  }
 }
 
 }  // namespace
@@ -236,13 +246,17 @@ int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size
   k_vg_heads<<<nb, 256, 0, stream>>>(keys_s, (uint32_t)n, head);
   CK(hipGetLastError());
   CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, head, slot, 0u, n, rocprim::plus<uint32_t>(), stream));
-  k_vg_average<<<nb, 256, 0, stream>>>(base, stride, nfields, keys_s, vals_s, head, slot, (uint32_t)n, d_out);
-  CK(hipGetLastError());
   uint32_t last[2];
   CK(hipMemcpyAsync(&last[0], slot + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   CK(hipMemcpyAsync(&last[1], head + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   CK(hipStreamSynchronize(stream));
-  *n_out = (size_t)last[0] + last[1];
+  const uint32_t ncells = last[0] + last[1];
+  uint32_t* pos = vals;   // the unsorted value array is free after the sort
+  k_vg_head_pos<<<nb, 256, 0, stream>>>(head, slot, (uint32_t)n, pos);
+  k_vg_average<<<(ncells + 3) / 4, 256, 0, stream>>>(base, stride, nfields, vals_s, pos, ncells, h_mm[6], d_out);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(stream));
+  *n_out = (size_t)ncells;
   return rc;
 #undef CK
 }

@@ -106,7 +106,11 @@ def test_voxel_downsample_matches_oracle(pcm):
         pts = _scan_for_downsample(seed)
         a = voxel_downsample(pts, leaf)
         b = reg.voxel_downsample(pts, leaf)
-        assert a.shape == b.shape and np.array_equal(a, b)        # double sums in input order on both sides: bit-equal
+        # double sums on both sides (sequential in the oracle, 64 interleaved partial sums + a fixed tree on the device):
+        # the float results agree except where a double rounding difference crosses a float rounding boundary
+        assert a.shape == b.shape
+        ulp = np.spacing(np.maximum(np.abs(a), 1e-3).astype(np.float32))
+        assert (np.abs(a - b) <= ulp).all() and (a == b).mean() > 0.9999
     with pytest.raises(pcm.PcmError):
         far = _scan_for_downsample(6); far[0, :3] = 1e7
         reg.voxel_downsample(far, 0.001)                           # index overflow, as PCL refuses it
