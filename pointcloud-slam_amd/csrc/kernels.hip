@@ -27,7 +27,7 @@
 // is written to HBM; the residual row goes through LDS into the tile's sums (float geometry, double
 // accumulation, fixed order).  The GN / LM state stays on the device for the whole align().
 // The kernel is VALU-bound: 2 463 vector instructions per wave, 1 672 of them in the
-// search loop, which a wave executes for the union of its lanes' needs.
+// search loop (which a wave executes for the union of its lanes' needs) and the plane fit behind it.
 //
 // Compiled with -ffp-contract=off: the float geometry that feeds discrete
 // decisions (voxel key, kNN order, plane test) must round like the reference's
