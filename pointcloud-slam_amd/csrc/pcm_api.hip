@@ -11,6 +11,8 @@
 #include "pclndt_host.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -997,14 +999,33 @@ int pcm_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resul
     if (rc != PCM_OK) return rc;
   }
   if (ctxs[0]->cfg.model == PCM_MODEL_NDT_OMP) {
-    // the Newton / line-search control flow of pclomp NDT is per object (a host decision per evaluation): no lock-step batch
+    // the Newton / line-search control flow of pclomp NDT is per object (a host decision per evaluation): no lock-step
+    // batch.  The objects are independent and each owns its stream, so up to 8 host threads drive them side by side and
+    // their (small) derivative kernels overlap on the device.
     std::vector<pcm_result> res((size_t)n);
-    int worst = PCM_OK;
+    std::vector<int> rcs((size_t)n, PCM_OK);
     for (int i = 0; i < n; i++) {
       if (ctxs[i]->cfg.model != PCM_MODEL_NDT_OMP) { ctxs[0]->err = "all contexts of a batch must share the model"; return PCM_ERR_INVALID_ARGUMENT; }
-      const int rc = pclndt_align(ctxs[i], guesses + 16 * (size_t)i, &res[i]);
-      if (rc != PCM_OK) { ctxs[0]->err = ctxs[i]->err; worst = rc; res[i].status = rc; }
+      for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) { ctxs[0]->err = "a context appears twice in the batch"; return PCM_ERR_INVALID_ARGUMENT; }
     }
+    const int nthreads = std::min(n, 8);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) break;
+        rcs[(size_t)i] = pclndt_align(ctxs[i], guesses + 16 * (size_t)i, &res[(size_t)i]);
+        if (rcs[(size_t)i] != PCM_OK) res[(size_t)i].status = rcs[(size_t)i];
+      }
+    };
+    if (nthreads <= 1) worker();
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+      for (auto& t : th) t.join();
+    }
+    int worst = PCM_OK;
+    for (int i = 0; i < n; i++) if (rcs[(size_t)i] != PCM_OK) { worst = rcs[(size_t)i]; if (i) ctxs[0]->err = ctxs[i]->err; }
     if (host_out) std::memcpy(host_out, res.data(), sizeof(pcm_result) * (size_t)n);
     if (device_out && hipMemcpy(device_out, res.data(), sizeof(pcm_result) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return PCM_ERR_HIP;
     return worst;
