@@ -439,9 +439,34 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     if (c->stream != c0->stream) {
       // inputs of the other contexts were produced on their own streams, which are idle after set_*()
     }
-    int rc = prepare(c);
-    if (rc != PCM_OK) { if (c != c0) c0->err = c->err; return rc; }
-    max_n = std::max(max_n, num_elements(c));
+  }
+  {
+    // per-object preparation (the scan's kNN index and covariances of the GICP family are the heavy part: a radix sort with
+    // host syncs per object): the objects are independent and own their streams, so up to 8 host threads prepare them side
+    // by side; nothing is shared but the device
+    std::vector<int> rcs((size_t)n, PCM_OK);
+    const int nthreads = (is_gicp(c0->cfg.model) && n > 1) ? std::min(n, 8) : 1;
+    bool distinct = true;
+    for (int i = 0; i < n && distinct; i++) for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) { distinct = false; break; }
+    if (nthreads <= 1 || !distinct) {
+      for (int i = 0; i < n; i++) rcs[(size_t)i] = prepare(ctxs[i]);
+    } else {
+      std::atomic<int> next{0};
+      auto worker = [&]() {
+        for (;;) {
+          const int i = next.fetch_add(1);
+          if (i >= n) break;
+          rcs[(size_t)i] = prepare(ctxs[i]);
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
+      for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < n; i++) {
+      if (rcs[(size_t)i] != PCM_OK) { if (ctxs[i] != c0) c0->err = ctxs[i]->err; return rcs[(size_t)i]; }
+      max_n = std::max(max_n, num_elements(ctxs[i]));
+    }
   }
   // GICP / VGICP: the covariance kernels of the contexts were queued on their own streams without a host
   // sync (they overlap on the device); the batch kernels below run on c0's stream and read their output
