@@ -35,6 +35,28 @@ def p2plane_case(seed, n_scan, m_map, optimizer):
                 scan_head=p.scan[:8].copy(), submap_head=p.submap[:8].copy())
 
 
+MODEL_CASES = [   # (name, oracle model, optimizer, oracle kwargs, dense submap?)
+    ("gicp_lm", "GICP", "LM", dict(voxel_resolution=0.5, max_corr_dist=2.0), False),
+    ("vgicp_d7_gn", "VGICP", "GN", dict(voxel_resolution=1.0, num_neighbors=7, max_iterations=12), False),
+    ("vgicp_mult_lm", "VGICP", "LM", dict(voxel_resolution=1.0, num_neighbors=1, voxel_mode=2, regularization="MIN_EIG", max_iterations=12), False),
+    ("vgicp_cuda_lm", "VGICP_CUDA", "LM", dict(voxel_resolution=1.0, num_neighbors=1, max_iterations=12), True),
+    ("ndt_d2d_lm", "NDT_D2D", "LM", dict(voxel_resolution=1.0, num_neighbors=7), True),
+    ("ndt_p2d_gn", "NDT_P2D", "GN", dict(voxel_resolution=1.0, num_neighbors=1, max_iterations=12), True),
+    ("ndt_omp_d7", "NDT_OMP", "LM", dict(voxel_resolution=1.0, num_neighbors=7, translation_eps=0.1, max_iterations=35), True),
+    ("ndt_omp_kdtree", "NDT_OMP", "LM", dict(voxel_resolution=1.0, num_neighbors=0, translation_eps=0.01, max_iterations=35), True),
+]
+
+
+def model_case(name, model, optimizer, kw, dense):
+    p = synth.make_pair(7, 4000, 40000, density=60.0 if dense else 8.0)
+    o = Oracle(model, optimizer, **kw)
+    o.set_input_target(p.submap)
+    o.set_input_source(p.scan)
+    r = o.align(p.guess)
+    return dict(T=result_T(r), iterations=r.iterations, converged=r.converged, num_linearize=r.num_linearize, num_compute_error=r.num_compute_error,
+                cost=r.cost, H=np.array(r.H[:]).reshape(6, 6))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cases = {}
@@ -46,6 +68,11 @@ def main():
         for k, v in c.items():
             flat[name + "/" + k] = np.asarray(v)
     np.savez_compressed(os.path.join(OUT, "p2plane_config1.npz"), **flat)
+    flat = {}
+    for name, model, opt, kw, dense in MODEL_CASES:
+        for k, v in model_case(name, model, opt, kw, dense).items():
+            flat[name + "/" + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "models_small.npz"), **flat)
     # corner KAT: exact pose known analytically
     sc, sm, T = synth.corner_scene(2000, 30000, seed=5)
     np.savez_compressed(os.path.join(OUT, "corner_kat.npz"), scan=sc, submap=sm, T=T)

@@ -173,6 +173,23 @@ def test_golden_vectors_reproduce(synth):
         assert dt < 0.10 and dr < np.deg2rad(1.0)      # noise-limited (2 cm range noise, 10k points, ground-dominated scan)
 
 
+def test_golden_vectors_of_the_other_models(synth):
+    """tests/golden/models_small.npz (tests/make_golden.py): one small registration per residual model, pinned against
+    regressions of the restatements (GICP, VGICP additive / multiplicative, VGICP of the CUDA core, NDT P2D / D2D, pclomp NDT)."""
+    import importlib.util
+    from oracle import Oracle
+    from oracle.loader import result_T
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    g = np.load(os.path.join(GOLD, "models_small.npz"))
+    for name, model, opt, kw, dense in mg.MODEL_CASES:
+        c = mg.model_case(name, model, opt, dict(kw, num_threads=2), dense)
+        assert int(c["iterations"]) == int(g[name + "/iterations"]) and int(c["converged"]) == int(g[name + "/converged"]), name
+        assert int(c["num_linearize"]) == int(g[name + "/num_linearize"]) and int(c["num_compute_error"]) == int(g[name + "/num_compute_error"]), name
+        assert np.allclose(c["T"], g[name + "/T"], rtol=0, atol=1e-8), name
+        assert np.allclose(c["H"], g[name + "/H"], rtol=1e-7, atol=1e-7 * np.abs(g[name + "/H"]).max()), name
+
+
 def test_edge_cases():
     from oracle import Oracle
     o = Oracle("P2PLANE", "GN")
