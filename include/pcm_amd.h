@@ -103,6 +103,7 @@ typedef struct pcm_config {
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
+#define PCM_FLAG_NO_FUSED_STEP 2    /* always take the GN step in its own launch (A/B checks) */
 
 /* out-parameters of align(): getFinalTransformation / hasConverged /
  * getFinalHessian / nr_iterations_  (lsq_registration_impl.hpp:40-79) */

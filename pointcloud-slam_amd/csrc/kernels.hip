@@ -202,6 +202,42 @@ __device__ inline void unpack_sums(const double* s, double* H, double* b, double
   *inliers = (int)s[28];
 }
 
+// The step of one pair done by the LAST workgroup of its k_linearize launch (rounds with one or two live pairs, where a
+// second launch costs more than the work): the same sums in the same order as k_finish_round (its 32 row groups are
+// walked four at a time by 256 threads), so a pair's result does not depend on which path ran its rounds.
+__device__ inline void finish_pair_in_place(const PairDesc& d, PairState* states, int pair, const LsqParams& lp, int nblocks, unsigned char* flags_row, double* s_grp /* 32 x 32 */,
+                                            double* s_tot /* 32 */) {
+  const int j = threadIdx.x & 31, g8 = threadIdx.x >> 5;
+  for (int r = g8; r < 32; r += 8) {
+    double v = 0.0;
+    if (j < kNumSums) {
+      int b = r;
+      for (; b + 96 < nblocks; b += 128) {
+        const double v0 = gload_d(d.partials + (size_t)b * kPartialStride + j), v1 = gload_d(d.partials + (size_t)(b + 32) * kPartialStride + j),
+                     v2 = gload_d(d.partials + (size_t)(b + 64) * kPartialStride + j), v3 = gload_d(d.partials + (size_t)(b + 96) * kPartialStride + j);
+        v = (((v + v0) + v1) + v2) + v3;
+      }
+      for (; b < nblocks; b += 32) v += gload_d(d.partials + (size_t)b * kPartialStride + j);
+    }
+    s_grp[r * kPartialStride + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums) {
+    double t = 0.0;
+    for (int k = 0; k < 32; k++) t += s_grp[k * kPartialStride + threadIdx.x];
+    s_tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PairState& st = states[pair];
+    double H[36], b[6], cost;
+    int inl;
+    unpack_sums(s_tot, H, b, &cost, &inl);
+    after_linearize(st, lp, H, b, cost, inl);
+    __hip_atomic_store(flags_row + pair, (unsigned char)(st.mode != MODE_DONE ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restrict__ descs, PairState* __restrict__ states, KernelParams kp, LsqParams lp, int trial_round,
                                                        int write_flags, unsigned char* __restrict__ flags_row, double* __restrict__ sums_out, unsigned int* __restrict__ queue,
                                                        int npairs) {
@@ -280,11 +316,17 @@ constexpr uint16_t kNoCell = 0xffffu;
     t_prev = t_now;                                                            \
   }
 
-template <bool STATS, bool TIMING, bool WRITE_PLANES, bool LIO>
+template <bool STATS, bool TIMING, bool WRITE_PLANES, bool LIO, bool FUSED = false>
 __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
-                                                      unsigned long long* __restrict__ stats) {
+                                                      unsigned long long* __restrict__ stats, LsqParams lp = LsqParams{}, unsigned char* __restrict__ flags_row = nullptr) {
   const int pair = PCM_PAIR_OF(kp, blockIdx.y);
-  if (states[pair].mode != MODE_LINEARIZE) return;
+  if (states[pair].mode != MODE_LINEARIZE) {
+    if constexpr (FUSED) {   // a pair that finished since the host last looked: its status byte of this round still has to land
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(flags_row + pair, (unsigned char)(states[pair].mode != MODE_DONE ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   const PairDesc d = descs[pair];
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (blockIdx.x * 256u >= d.src.num_points) return;
@@ -695,6 +737,25 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
       for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
       gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
     }
+    if constexpr (FUSED) {
+      // arrival ticket: the workgroup that completes the pair's round sums the partial rows and takes the GN step
+      __shared__ unsigned int s_last;
+      __threadfence();                    // this workgroup's partial row is visible device-wide before its ticket
+      __syncthreads();
+      const int nblocks = (int)((d.src.num_points + 255u) / 256u);
+      if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)(nblocks - 1)) ? 1u : 0u;
+        if (s_last) __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next round
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();                  // acquire: the other workgroups' rows
+        double* f_grp = reinterpret_cast<double*>(s_pts);          // 32 x 32 doubles; s_pts is free by now
+        double* f_tot = f_grp + 32 * kPartialStride;
+        finish_pair_in_place(d, const_cast<PairState*>(states), pair, lp, nblocks, flags_row, f_grp, f_tot);
+      }
+    }
   }
   PCM_STAMP(6)   // queued double-precision fits + residual + workgroup reduction
   if (TIMING && threadIdx.x == 0) atomicAdd(&stats[15], 1ull);
@@ -708,6 +769,12 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
       if (wave == 0) { atomicAdd(&stats[2], use_lds ? 1ull : 0ull); atomicAdd(&stats[3], 1ull); }
     }
   }
+}
+
+// GN rounds with very few live pairs: the search kernel's last workgroup per pair also takes the step (no k_finish_round launch)
+void launch_linearize_fused(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, unsigned char* d_flags_row) {
+  dim3 grid((unsigned)kp.tiles_per_pair, (unsigned)npairs);
+  k_linearize<false, false, false, false, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, nullptr, lp, d_flags_row);
 }
 
 void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,

@@ -544,11 +544,14 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     }
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
+    // late GN rounds (one or two pairs left): the last workgroup of a pair's launch takes its step, no second launch
+    const bool fuse = use_list && !is_lm && !ndt && !gicp && !counters_on && !timing_on && nl <= 2 && kp.do_step && !(g.flags & PCM_FLAG_NO_FUSED_STEP);
     if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), false);
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
+    else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
-    launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
+    if (!fuse) launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
     if (is_lm) {
       if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), true);
       else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, true);

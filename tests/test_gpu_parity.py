@@ -277,3 +277,26 @@ def test_batch_window_equals_singles(pcm, synth, optimizer):
         batch = pcm.align_batch(regs, np.stack([p.guess for p in pairs]))
         for s, b in zip(singles, batch):
             assert np.array_equal(s.T64, b.T64) and s.iterations == b.iterations and s.converged == b.converged
+
+
+def test_fused_step_equals_separate_step(pcm, synth):
+    """Late GN rounds take the step in the search kernel's last workgroup (PCM_FLAG_NO_FUSED_STEP = 2 turns that off):
+    same sums in the same order, so the results are bit-identical; also against the oracle."""
+    from oracle import Oracle
+    from oracle.loader import result_T
+    pairs = [synth.make_pair(80 + i, 3000 + 700 * i, 30000 + 3000 * i) for i in range(5)]
+    out = {}
+    for flags in (0, 2):
+        regs = []
+        for p in pairs:
+            g = pcm.P2PlaneRegistration(0, optimizer="GN", flags=flags)
+            g.set_input_target(p.submap); g.set_input_source(p.scan); regs.append(g)
+        out[flags] = pcm.align_batch(regs, np.stack([p.guess for p in pairs])), [g.align(p.guess) for g, p in zip(regs, pairs)]
+    for a, b, sa, sb in zip(out[0][0], out[2][0], out[0][1], out[2][1]):
+        assert np.array_equal(a.T64, b.T64) and a.iterations == b.iterations
+        assert np.array_equal(sa.T64, a.T64) and np.array_equal(sb.T64, b.T64)
+    for p, a in zip(pairs, out[0][0]):
+        o = Oracle("P2PLANE", "GN"); o.set_input_target(p.submap); o.set_input_source(p.scan)
+        r = o.align(p.guess)
+        dt, dr = pose_error(result_T(r), a.T64)
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD and a.iterations == r.iterations
