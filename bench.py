@@ -82,6 +82,7 @@ def main():
                     help="independent batches in flight per GPU (each on its own stream / host thread), so the few slow-converging "
                          "pairs of one batch run under the bulk of the next")
     ap.add_argument("--window", type=int, default=0, help="pairs of a sub-batch iterating at a time (0 = all): finished pairs hand their slot to queued ones")
+    ap.add_argument("--flags", type=int, default=0, help="pcm_config.flags (A/B switches; never change a result)")
     ap.add_argument("--scan-points", type=int, default=100000)
     ap.add_argument("--map-points", type=int, default=1000000)
     ap.add_argument("--optimizer", default="GN", choices=["GN", "LM"])
@@ -128,7 +129,7 @@ def main():
         d_map = torch.from_numpy(submap).to(dev)
         d_inputs.append((d_scan, d_map))
         r = pcm.P2PlaneRegistration(local_rank, optimizer=args.optimizer, voxel_resolution=cfg["voxel_resolution"],
-                                    num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source, batch_window=args.window)
+                                    num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source, batch_window=args.window, flags=args.flags)
         r.set_input_target(d_map)
         r.set_input_source(d_scan)
         regs.append(r)
