@@ -103,7 +103,8 @@ typedef struct pcm_config {
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
-#define PCM_FLAG_NO_FUSED_STEP 2    /* always take the GN step in its own launch (A/B checks) */
+#define PCM_FLAG_FUSED_STEP 2       /* late GN rounds: take the step in the search kernel's last workgroup instead of a second launch
+                                     * (measured slower: the agent-scope release/acquire pair flushes L2 under the other stream; off by default) */
 
 /* out-parameters of align(): getFinalTransformation / hasConverged /
  * getFinalHessian / nr_iterations_  (lsq_registration_impl.hpp:40-79) */

@@ -280,7 +280,7 @@ def test_batch_window_equals_singles(pcm, synth, optimizer):
 
 
 def test_fused_step_equals_separate_step(pcm, synth):
-    """Late GN rounds take the step in the search kernel's last workgroup (PCM_FLAG_NO_FUSED_STEP = 2 turns that off):
+    """With PCM_FLAG_FUSED_STEP (= 2) late GN rounds take the step in the search kernel's last workgroup:
     same sums in the same order, so the results are bit-identical; also against the oracle."""
     from oracle import Oracle
     from oracle.loader import result_T
