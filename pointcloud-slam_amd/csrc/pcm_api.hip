@@ -758,6 +758,13 @@ pcm_ctx* pcm_create(int device, const pcm_config* cfg) {
     c->device = -1;
     return c;
   }
+  {   // keep freed scratch in the device's stream-ordered pool instead of returning it to the driver at every sync
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+      uint64_t keep = ~0ull;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+  }
   c->own_stream = true;
   return c;
 }

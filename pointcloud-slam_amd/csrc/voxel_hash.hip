@@ -134,6 +134,9 @@ __global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* _
 }
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+// scratch arrays come from the device's stream-ordered memory pool (hipMallocAsync): after the first frames an allocation
+// is a pool hit, no driver call and no implicit device synchronisation -- the sliding map rebuilds every frame
+static inline void sfree(hipStream_t stream, void* p) { if (p) (void)hipFreeAsync(p, stream); }
 
 // ---------------------------------------------------------------------------
 // Sliding-map eviction: IVox keeps its voxels in a least-recently-touched list and
@@ -240,23 +243,23 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     hipError_t e_ = (x);                                                         \
     if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
   } while (0)
-  CK(hipMalloc(&keys, sizeof(uint64_t) * n));
-  CK(hipMalloc(&keys_s, sizeof(uint64_t) * n));
-  CK(hipMalloc(&idx, sizeof(uint32_t) * n));
-  CK(hipMalloc(&idx_s, sizeof(uint32_t) * n));
-  CK(hipMalloc(&vflag, sizeof(uint32_t) * n));
-  CK(hipMalloc(&vrank, sizeof(uint32_t) * n));
-  CK(hipMalloc(&d_flags, 2 * sizeof(int)));
+  CK(hipMallocAsync(&keys, sizeof(uint64_t) * n, stream));
+  CK(hipMallocAsync(&keys_s, sizeof(uint64_t) * n, stream));
+  CK(hipMallocAsync(&idx, sizeof(uint32_t) * n, stream));
+  CK(hipMallocAsync(&idx_s, sizeof(uint32_t) * n, stream));
+  CK(hipMallocAsync(&vflag, sizeof(uint32_t) * n, stream));
+  CK(hipMallocAsync(&vrank, sizeof(uint32_t) * n, stream));
+  CK(hipMallocAsync(&d_flags, 2 * sizeof(int), stream));
   CK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), stream));
   k_point_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, res, inv_res, coord_mode, keys, idx, d_flags);
   CK(hipGetLastError());
   CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
-  CK(hipMalloc(&tmp, tmp_bytes));
+  CK(hipMallocAsync(&tmp, tmp_bytes, stream));
   CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
   k_head_flags<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, n, vflag, reinterpret_cast<unsigned int*>(d_flags + 1));
   CK(hipGetLastError());
   CK(rocprim::exclusive_scan(nullptr, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-  CK(hipMalloc(&tmp2, tmp2_bytes));
+  CK(hipMallocAsync(&tmp2, tmp2_bytes, stream));
   CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
   {
     int h_flags[2];
@@ -283,23 +286,23 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     hipError_t e_ = (x);                                                         \
     if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc2 = PCM_ERR_HIP; goto evict_done; } \
   } while (0)
-      CK2(hipMalloc(&vlast, sizeof(uint32_t) * nvox));
-      CK2(hipMalloc(&vsorted, sizeof(uint32_t) * nvox));
-      CK2(hipMalloc(&alive, sizeof(uint32_t) * n));
-      CK2(hipMalloc(&pos, sizeof(uint32_t) * n));
-      CK2(hipMalloc(&tmp_log, sizeof(float4) * n));
+      CK2(hipMallocAsync(&vlast, sizeof(uint32_t) * nvox, stream));
+      CK2(hipMallocAsync(&vsorted, sizeof(uint32_t) * nvox, stream));
+      CK2(hipMallocAsync(&alive, sizeof(uint32_t) * n, stream));
+      CK2(hipMallocAsync(&pos, sizeof(uint32_t) * n, stream));
+      CK2(hipMallocAsync(&tmp_log, sizeof(float4) * n, stream));
       CK2(hipMemsetAsync(vlast, 0, sizeof(uint32_t) * nvox, stream));
       k_voxel_last<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, vflag, vrank, n, vlast);
       CK2(hipGetLastError());
       CK2(rocprim::radix_sort_keys(nullptr, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
-      CK2(hipMalloc(&tmp3, tmp3_bytes));
+      CK2(hipMallocAsync(&tmp3, tmp3_bytes, stream));
       CK2(rocprim::radix_sort_keys(tmp3, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
       CK2(hipMemcpyAsync(&cutoff, vsorted + (nvox - keep), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       CK2(hipStreamSynchronize(stream));
       k_mark_alive<<<cdiv(n, 256), 256, 0, stream>>>(idx_s, vflag, vrank, vlast, cutoff, n, alive);
       CK2(hipGetLastError());
       CK2(rocprim::exclusive_scan(nullptr, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-      CK2(hipMalloc(&tmp4, tmp4_bytes));
+      CK2(hipMallocAsync(&tmp4, tmp4_bytes, stream));
       CK2(rocprim::exclusive_scan(tmp4, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
       k_compact_log<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, alive, pos, n, tmp_log);
       CK2(hipGetLastError());
@@ -310,9 +313,9 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       CK2(hipStreamSynchronize(stream));
       *n_inout = h_tail[0] + h_tail[1];
     evict_done:
-      hipFree(vlast); hipFree(vsorted); hipFree(alive); hipFree(pos); hipFree(tmp_log); hipFree(tmp3); hipFree(tmp4);
+      sfree(stream, vlast); sfree(stream, vsorted); sfree(stream, alive); sfree(stream, pos); sfree(stream, tmp_log); sfree(stream, tmp3); sfree(stream, tmp4);
 #undef CK2
-      hipFree(keys); hipFree(keys_s); hipFree(idx); hipFree(idx_s); hipFree(vflag); hipFree(vrank); hipFree(d_flags); hipFree(tmp); hipFree(tmp2);
+      sfree(stream, keys); sfree(stream, keys_s); sfree(stream, idx); sfree(stream, idx_s); sfree(stream, vflag); sfree(stream, vrank); sfree(stream, d_flags); sfree(stream, tmp); sfree(stream, tmp2);
       if (rc2 != PCM_OK) return rc2;
       return build_target_map(stream, d_pts, n_inout, res, coord_mode, want_gauss, 0u, map, err, keep_order);   // now within capacity
     }
@@ -341,7 +344,11 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(stream));
-    if (keep_order) { map->order = idx_s; idx_s = nullptr; }
+    if (keep_order) {   // a persistent copy (the scratch arrays come from the stream-ordered pool)
+      CK(hipMalloc(&map->order, sizeof(uint32_t) * (size_t)n));
+      CK(hipMemcpyAsync(map->order, idx_s, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+      CK(hipStreamSynchronize(stream));
+    }
     map->cap = cap;
     map->num_voxels = nvox;
     map->num_bricks = nbricks;
@@ -352,7 +359,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     map->valid = true;
   }
 done:
-  hipFree(keys); hipFree(keys_s); hipFree(idx); hipFree(idx_s); hipFree(vflag); hipFree(vrank); hipFree(d_flags); hipFree(tmp); hipFree(tmp2);
+  sfree(stream, keys); sfree(stream, keys_s); sfree(stream, idx); sfree(stream, idx_s); sfree(stream, vflag); sfree(stream, vrank); sfree(stream, d_flags); sfree(stream, tmp); sfree(stream, tmp2);
   if (rc != PCM_OK) map->release();
   return rc;
 #undef CK
@@ -516,14 +523,14 @@ int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, c
     hipError_t e_ = (x);                                                         \
     if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
   } while (0)
-  CK(hipMalloc(&world, sizeof(float4) * n));
-  CK(hipMalloc(&buf, sizeof(uint32_t) * 4 * (size_t)n));
+  CK(hipMallocAsync(&world, sizeof(float4) * n, stream));
+  CK(hipMallocAsync(&buf, sizeof(uint32_t) * 4 * (size_t)n, stream));
   {
     uint32_t *f1 = buf, *f2 = buf + n, *p1 = buf + 2 * (size_t)n, *p2 = buf + 3 * (size_t)n;
     k_map_filter<<<cdiv(n, 256), 256, 0, stream>>>(scan, n, s, filter_size_map, nn, map_pts, world, f1, f2);
     CK(hipGetLastError());
     CK(rocprim::exclusive_scan(nullptr, tmp_bytes, f1, p1, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-    CK(hipMalloc(&tmp, tmp_bytes));
+    CK(hipMallocAsync(&tmp, tmp_bytes, stream));
     CK(rocprim::exclusive_scan(tmp, tmp_bytes, f1, p1, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     CK(rocprim::exclusive_scan(tmp, tmp_bytes, f2, p2, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     CK(hipMemcpyAsync(&tails[0], f1 + (n - 1), 4, hipMemcpyDeviceToHost, stream));
@@ -538,7 +545,7 @@ int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, c
     *num_added = n1 + n2;
   }
 done:
-  hipFree(world); hipFree(buf); hipFree(tmp);
+  sfree(stream, world); sfree(stream, buf); sfree(stream, tmp);
   return rc;
 #undef CK
 }
