@@ -75,8 +75,8 @@ def cpu_baseline(pairs, cfg, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs-per-gpu", type=int, default=32)
     ap.add_argument("--pipeline", type=int, default=2,
                     help="independent batches in flight per GPU (each on its own stream / host thread), so the few slow-converging "
