@@ -84,7 +84,6 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="pairs of a sub-batch iterating at a time (0 = all): finished pairs hand their slot to queued ones")
     ap.add_argument("--schedule", default="iters", choices=["even", "iters"],
                     help="sub-batch membership: contiguous halves, or (after the cold pass) the slow-converging pairs together so that the sub-batches cost the same")
-    ap.add_argument("--cut", type=int, default=0, help="with --schedule iters: size of the slow sub-batch (0 = by the cost model)")
     ap.add_argument("--flags", type=int, default=0, help="pcm_config.flags (A/B switches; never change a result)")
     ap.add_argument("--scan-points", type=int, default=100000)
     ap.add_argument("--map-points", type=int, default=1000000)
@@ -218,7 +217,7 @@ def main():
         def cost(its):   # rounds x (launch + step latency) + pair-rounds x device time, in microseconds
             return 0.0 if len(its) == 0 else 40.0 * its.max() + 8.0 * its.sum()
 
-        cut = args.cut if 0 < args.cut < n_local else min(range(1, n_local), key=lambda p: abs(cost(it[order[:p]]) - cost(it[order[p:]])))
+        cut = min(range(1, n_local), key=lambda p: abs(cost(it[order[:p]]) - cost(it[order[p:]])))
         regs = [regs[i] for i in order]; d_inputs = [d_inputs[i] for i in order]; pairs = [pairs[i] for i in order]
         guesses = np.ascontiguousarray(guesses[order])
         groups[:] = [list(range(0, cut)), list(range(cut, n_local))]
