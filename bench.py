@@ -82,8 +82,6 @@ def main():
                     help="independent batches in flight per GPU (each on its own stream / host thread), so the few slow-converging "
                          "pairs of one batch run under the bulk of the next")
     ap.add_argument("--window", type=int, default=0, help="pairs of a sub-batch iterating at a time (0 = all): finished pairs hand their slot to queued ones")
-    ap.add_argument("--schedule", default="iters", choices=["even", "iters"],
-                    help="sub-batch membership: contiguous halves, or (after the cold pass) the slow-converging pairs together so that the sub-batches cost the same")
     ap.add_argument("--flags", type=int, default=0, help="pcm_config.flags (A/B switches; never change a result)")
     ap.add_argument("--scan-points", type=int, default=100000)
     ap.add_argument("--map-points", type=int, default=1000000)
@@ -159,11 +157,10 @@ def main():
         for i in idx:
             regs[i].set_input_source(d_inputs[i][0])
         res = pcm.align_batch([regs[i] for i in idx], guesses[lo:hi], device_out=d_results.data_ptr() + lo * rec)
-        if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per sub-batch; every slot sends the
-            # rank's whole fixed-size record block, of which its own sub-batch is the fresh part: sub-batch sizes differ per rank)
+        if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per sub-batch)
             with torch.cuda.stream(streams[j]):
-                got = sharding.gather_records(d_results, world, group=pgs[j])
-                d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got[:, lo * rec:hi * rec])
+                got = sharding.gather_records(d_results[lo * rec:hi * rec], world, group=pgs[j])
+                d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got)
             streams[j].synchronize()
         return res
 
@@ -206,24 +203,6 @@ def main():
     res = run_steps(1)
     fence()
     t_cold = time.perf_counter() - t0
-
-    if args.schedule == "iters" and S == 2:
-        # Sub-batch membership from the pass just made (in a scan stream: from the previous frame).  A sub-batch runs in lock
-        # step for as many rounds as its slowest pair; putting the slow-converging pairs together and cutting where the two
-        # sub-batches cost the same keeps both host threads busy to the end.  Results do not depend on the grouping.
-        it = np.array([r.num_linearize for r in res])
-        order = np.argsort(-it, kind="stable")
-
-        def cost(its):   # rounds x (launch + step latency) + pair-rounds x device time, in microseconds
-            return 0.0 if len(its) == 0 else 40.0 * its.max() + 8.0 * its.sum()
-
-        cut = min(range(1, n_local), key=lambda p: abs(cost(it[order[:p]]) - cost(it[order[p:]])))
-        regs = [regs[i] for i in order]; d_inputs = [d_inputs[i] for i in order]; pairs = [pairs[i] for i in order]
-        guesses = np.ascontiguousarray(guesses[order])
-        groups[:] = [list(range(0, cut)), list(range(cut, n_local))]
-        sched = {"kind": "iters", "sub_batch_sizes": [cut, n_local - cut]}
-    else:
-        sched = {"kind": "even", "sub_batch_sizes": [len(gp) for gp in groups]}
 
     t0 = time.perf_counter()
     for _ in range(max(1, args.warmup - 1)):
@@ -293,7 +272,7 @@ def main():
             "dtype": "f32 geometry / f64 accumulate", "data": "synthetic",
             "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence)"
                                    % (args.scan_points, args.map_points, args.optimizer),
-                       "pairs_per_gpu": n_local, "batches_in_flight": S, "sub_batches": sched, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
+                       "pairs_per_gpu": n_local, "batches_in_flight": S, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
                        "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), RCCL all_gather of poses" % world,
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen},
