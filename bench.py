@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--sort-source", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the measured path); gloo only to rehearse the N>1 control flow with several ranks sharing one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,10 +118,14 @@ def main():
     from pointcloud_slam_amd import capi
     import ctypes
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     # ---- residency: scans + submaps in HBM, voxel hashes built ------------------------------------
     regs, guesses = [], []
@@ -128,7 +134,7 @@ def main():
         d_scan = torch.from_numpy(scan).to(dev)
         d_map = torch.from_numpy(submap).to(dev)
         d_inputs.append((d_scan, d_map))
-        r = pcm.P2PlaneRegistration(local_rank, optimizer=args.optimizer, voxel_resolution=cfg["voxel_resolution"],
+        r = pcm.P2PlaneRegistration(dev_index, optimizer=args.optimizer, voxel_resolution=cfg["voxel_resolution"],
                                     num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source, batch_window=args.window, flags=args.flags)
         r.set_input_target(d_map)
         r.set_input_source(d_scan)
@@ -171,7 +177,7 @@ def main():
 
         def worker(j):
             try:
-                torch.cuda.set_device(local_rank)
+                torch.cuda.set_device(dev_index)
                 if stagger_s > 0 and j > 0:
                     time.sleep(j * stagger_s)
                 for _ in range(k):
@@ -240,6 +246,13 @@ def main():
     kbar = sc["candidates"] / max(1, sc["point_passes"])
     probes = sc["slots_probed"] / max(1, sc["point_passes"])
 
+    gathered_ok = None
+    if world > 1:   # untimed check of the exchange: own block round-trips, every rank's poses arrived
+        allrec = d_gather.view(world, n_local * rec)
+        if not torch.equal(allrec[rank], d_results):
+            raise SystemExit("rank %d: gathered block differs from the local results" % rank)
+        gathered_ok = sum(int(r["status"] == 0) for r in sharding.records_to_results(allrec.reshape(-1)))
+
     total_regs = args.steps * n_local * world
     value = total_regs / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -273,9 +286,9 @@ def main():
             "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence)"
                                    % (args.scan_points, args.map_points, args.optimizer),
                        "pairs_per_gpu": n_local, "batches_in_flight": S, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
-                       "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), RCCL all_gather of poses" % world,
+                       "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
-                       "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen},
+                       "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_linearize", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_point_pass": b_pi, "candidates_per_point": kbar, "slots_probed_per_point": probes,

@@ -41,6 +41,12 @@ def gather_records(local_records, world: int, group=None):
     import torch.distributed as dist
     if world == 1:
         return local_records.view(1, -1)
+    if local_records.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks: gloo moves host bytes
+        host = local_records.cpu()
+        out = torch.empty(world * host.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.view(world, -1).to(local_records.device)
     out = torch.empty(world * local_records.numel(), dtype=torch.uint8, device=local_records.device)
     dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)
     return out.view(world, -1)
