@@ -26,6 +26,7 @@ for t in range(a.pairs):
     g.set_input_target(p.submap); g.set_input_source(p.scan)
     T = p.guess.astype(np.float64)
     c0, H0, b0 = o.linearize(T)
+    inl0 = int(o.num_inliers)   # at the guess, like the GPU figure beside it
     c1, H1, b1, inl = g.evaluate_cost(T)
     pl0, sel0 = o.get_planes(len(p.scan))
     pl1 = g.get_planes(len(p.scan))
@@ -35,7 +36,9 @@ for t in range(a.pairs):
     ro, rg = o.align(p.guess), g.align(p.guess)
     dt, dr = pose_error(result_T(ro), rg.T64)
     hrel = float(np.abs(H1 - H0).max() / max(np.abs(H0).max(), 1e-300))
-    rows.append(dict(t=t, n=n_scan, m=m_map, dens=dens, nn=nn, opt=opt, res=res, bad_planes=bad, inl=(int(inl), int(o.num_inliers)), dt=dt, dr=dr, it=(rg.iterations, ro.iterations), H_rel=hrel))
+    rows.append(dict(t=t, n=n_scan, m=m_map, dens=dens, nn=nn, opt=opt, res=res, bad_planes=bad, inl=(int(inl), inl0), dt=dt, dr=dr, it=(rg.iterations, ro.iterations), H_rel=hrel))
     worst["plane_mismatch_points"] += bad; worst["dt"] = max(worst["dt"], dt); worst["dr"] = max(worst["dr"], dr)
     worst["iter_mismatch"] += int(rg.iterations != ro.iterations); worst["H_rel"] = max(worst["H_rel"], hrel)
+    worst["inlier_mismatch"] = worst.get("inlier_mismatch", 0) + int(int(inl) != inl0)
+    print("pair %d done" % t, file=sys.stderr, flush=True)
 print(json.dumps({"worst": worst, "rows": rows}, indent=1))
