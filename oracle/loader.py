@@ -271,3 +271,33 @@ def voxel_downsample(points, leaf):
 
 def result_T(res) -> np.ndarray:
     return np.array(res.T64[:], dtype=np.float64).reshape(4, 4)
+
+
+def gicp_bfgs_fdf(src, tgt, idx_src, idx_tgt, maha, base_T, x, mode=2):
+    """orc_gicp_bfgs_fdf: (f, g[6]) of pclomp's GICP-BFGS functor.  src/tgt: (N,F) float32 (x y z first); maha: (N_src,16)
+    float32, column-major Matrix4f per SOURCE point; base_T: 4x4; x: 6 doubles; mode 0 = f, 1 = df, 2 = fdf."""
+    L = lib()
+    src = np.ascontiguousarray(src, np.float32); tgt = np.ascontiguousarray(tgt, np.float32)
+    assert src.shape[1] == tgt.shape[1]
+    idx_src = np.ascontiguousarray(idx_src, np.int32); idx_tgt = np.ascontiguousarray(idx_tgt, np.int32)
+    maha = np.ascontiguousarray(maha, np.float32).reshape(-1, 16)
+    base = np.ascontiguousarray(base_T, np.float32).reshape(16); xx = np.ascontiguousarray(x, np.float64).reshape(6)
+    f = C.c_double(0.0); g = np.zeros(6, np.float64)
+    L.orc_gicp_bfgs_fdf.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.POINTER(C.c_double), C.c_void_p]
+    L.orc_gicp_bfgs_fdf.restype = C.c_int
+    rc = L.orc_gicp_bfgs_fdf(src.ctypes.data, tgt.ctypes.data, src.shape[1], idx_src.ctypes.data, idx_tgt.ctypes.data, len(idx_src), maha.ctypes.data,
+                             base.ctypes.data, xx.ctypes.data, int(mode), C.byref(f), g.ctypes.data)
+    if rc != 0:
+        raise ValueError("orc_gicp_bfgs_fdf: %d" % rc)
+    return f.value, g
+
+
+def gicp_bfgs_apply_state(base_T, x):
+    L = lib()
+    base = np.ascontiguousarray(base_T, np.float32).reshape(16); xx = np.ascontiguousarray(x, np.float64).reshape(6)
+    T = np.zeros(16, np.float32)
+    L.orc_gicp_bfgs_apply_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_gicp_bfgs_apply_state.restype = None
+    L.orc_gicp_bfgs_apply_state(base.ctypes.data, xx.ctypes.data, T.ctypes.data)
+    return T.reshape(4, 4)

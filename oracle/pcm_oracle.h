@@ -93,6 +93,12 @@ typedef struct orc_imu_pose { double offset_time, acc[3], gyr[3], vel[3], pos[3]
 void orc_undistort(float *pts, long n, long stride_floats, long time_index, const orc_imu_pose *poses, int npose, const orc_lio_state *st);
 /* pcl::VoxelGrid down-sampling of a scan (laser_mapping.cc:323-328): out holds up to n records; returns the count, -1 on index overflow */
 long orc_voxel_downsample(const float *pts, long n, long stride_floats, float leaf, float *out);
+
+/* pclomp GICP-BFGS functor (ndt_omp/include/pclomp/gicp_omp_impl.hpp:246-365, :519-529, :125-176); orc_gicp_bfgs.c */
+void orc_gicp_bfgs_apply_state(const float base[16], const double x[6], float T[16]);
+void orc_gicp_bfgs_r_derivative(const double x[6], const double R[9], double g[6]);
+int orc_gicp_bfgs_fdf(const float *src, const float *tgt, long stride_f, const int *idx_src, const int *idx_tgt, long m, const float *maha,
+                      const float base[16], const double x[6], int mode, double *f_out, double g[6]);
 /* LaserMapping::ObsModel (jueying_lio/src/laser_mapping.cc:592-701) + the reduction the IEKF
  * applies to it, HTH = h_x^T h_x and h_x^T h (esekfom.hpp:1687,1706).  converge != 0: re-match
  * (5-NN + plane fit); converge == 0: re-use the planes of the previous call.  Returns 0, or -1

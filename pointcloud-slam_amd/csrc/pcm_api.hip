@@ -203,7 +203,6 @@ int prepare(pcm_ctx* c) {
     if (!c->pleaf_valid) {
       if (c->pleaf_cap < c->map.num_voxels) {
         if (c->pleaf) hipFree(c->pleaf);
-    if (c->pre_arena) hipFree(c->pre_arena);
         c->pleaf = nullptr; c->pleaf_cap = 0;
         HIPCK(c, hipMalloc(&c->pleaf, sizeof(PclLeaf) * (size_t)c->map.num_voxels));
         c->pleaf_cap = c->map.num_voxels;
@@ -288,11 +287,6 @@ int prepare(pcm_ctx* c) {
     const size_t ncorr = c->cfg.model == PCM_MODEL_VGICP_CUDA ? 0 : c->src.n * (size_t)(c->cfg.model == PCM_MODEL_VGICP ? c->cfg.num_neighbors : 1);
     if (c->maha_cap < ncorr) {
       if (c->maha) hipFree(c->maha);
-    if (c->pleaf) hipFree(c->pleaf);
-    if (c->pre_arena) hipFree(c->pre_arena);
-    if (c->ndt_partials) hipFree(c->ndt_partials);
-    if (c->ndt_out) hipFree(c->ndt_out);
-    if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
       c->maha = nullptr; c->maha_cap = 0;
       HIPCK(c, hipMalloc(&c->maha, sizeof(double) * 6 * ncorr));
       c->maha_cap = ncorr;

@@ -57,3 +57,23 @@ def test_bad_configs_are_rejected(pcm):
         pcm.VgicpRegistration(0, voxel_mode=3)
     with pytest.raises(pcm.PcmError):
         pcm.PclNdtRegistration(0, ndt_outlier_ratio=1.5)
+
+
+def test_preprocess_arena_survives_a_registration_on_the_same_context(pcm):
+    """The scan pre-processing arena of a context must stay valid across (re)allocations of the
+    registration buffers of that context (GICP correspondence buffers, pclomp NDT leaves)."""
+    rng = np.random.default_rng(5)
+    scan = rng.uniform(-8, 8, (6000, 4)).astype(np.float32)
+    tgt = rng.uniform(-10, 10, (30000, 3)).astype(np.float32); tgt[:, 2] *= 0.05
+    src = tgt[::5] + np.array([0.05, -0.03, 0.01], np.float32)
+    for cls in (pcm.GicpRegistration, pcm.VgicpRegistration, pcm.PclNdtRegistration):
+        g = cls(0, max_iterations=3)
+        first = g.voxel_downsample(scan, 0.5)                 # arena allocated
+        g.set_input_target(tgt); g.set_input_source(src)
+        g.align(np.eye(4, dtype=np.float32))                  # registration buffers allocated
+        g.set_input_target(np.concatenate([tgt, tgt + 0.01]))
+        g.set_input_source(np.concatenate([src, src + 0.01]))
+        g.align(np.eye(4, dtype=np.float32))                  # ... and grown
+        again = g.voxel_downsample(scan, 0.5)
+        assert np.array_equal(first, again)
+        del g                                                  # every buffer released exactly once
