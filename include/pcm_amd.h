@@ -256,6 +256,17 @@ int pcm_undistort(pcm_ctx *ctx, void *points, size_t n, size_t stride_bytes, siz
  * Replaces voxel_scan_.filter() of LaserMapping::Run (jueying_lio/src/laser_mapping.cc:323-328). */
 int pcm_voxel_downsample(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory, float leaf_size, void *out, size_t capacity_points, size_t *n_out);
 
+/* pclomp GICP-BFGS (jueying_slam's GICP_OMP option): the functor its BFGS minimises, evaluated on the device.
+ * set_correspondences packs the outer iteration's correspondence set once -- tmp_src_/tmp_tgt_ (records of
+ * stride_bytes, x y z first), tmp_idx_src_/tmp_idx_tgt_ (m indices, in range: checked for host memory only) and
+ * mahalanobis_ (n_src Matrix4f, column-major, indexed by the source index) -- as estimateRigidTransformationBFGS sets
+ * them (ndt_omp/include/pclomp/gicp_omp_impl.hpp:199-203, filled at :430-480).
+ * fdf evaluates OptimizationFunctorWithIndices at x = (tx ty tz roll pitch yaw) on top of base_transformation_
+ * (`base_T`, row-major 4x4): mode 0 = operator() (:246-274, f only), 1 = df (:278-327, g only), 2 = fdf (:331-365). */
+int pcm_gicp_bfgs_set_correspondences(pcm_ctx *ctx, const void *src, size_t n_src, const void *tgt, size_t n_tgt, size_t stride_bytes, const int32_t *idx_src,
+                                      const int32_t *idx_tgt, size_t m, const float *mahalanobis, int memory);
+int pcm_gicp_bfgs_fdf(pcm_ctx *ctx, const float *base_T, const double *x, int mode, double *f, double *g);
+
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel
  * launches, no host round trip per iteration.  `guesses` = n x 16 floats.

@@ -781,6 +781,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->maha) hipFree(c->maha);
     if (c->pleaf) hipFree(c->pleaf);
     if (c->pre_arena) hipFree(c->pre_arena);
+    if (c->bfgs) hipFree(c->bfgs);
     if (c->ndt_partials) hipFree(c->ndt_partials);
     if (c->ndt_out) hipFree(c->ndt_out);
     if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
@@ -914,6 +915,115 @@ int pcm_undistort(pcm_ctx* c, void* points, size_t n, size_t stride, size_t time
   if (rc != PCM_OK) return rc;
   if (memory == PCM_MEM_HOST) HIPCK(c, hipMemcpyAsync(points, d_pts, n * stride, hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
+  return PCM_OK;
+}
+
+// ---- pclomp GICP-BFGS functor (ndt_omp/include/pclomp/gicp_omp_impl.hpp) ------------------------------------------
+namespace {
+
+// applyState (:519-529): t <- R t with R from AngleAxisf(z) * AngleAxisf(y) * AngleAxisf(x) (a float quaternion product), then the translation
+void bfgs_apply_state(const float* base, const double* x, float* T) {
+  auto axis_quat = [](float ang, int k, float* q) { const float h = 0.5f * ang; q[0] = q[1] = q[2] = 0.f; q[k] = sinf(h); q[3] = cosf(h); };
+  auto mul = [](const float* a, const float* b, float* r) {
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  };
+  float qz[4], qy[4], qx[4], qa[4], q[4];
+  axis_quat((float)x[5], 2, qz); axis_quat((float)x[4], 1, qy); axis_quat((float)x[3], 0, qx);
+  mul(qz, qy, qa); mul(qa, qx, q);
+  const float tx = 2.f * q[0], ty = 2.f * q[1], tz = 2.f * q[2];
+  const float twx = tx * q[3], twy = ty * q[3], twz = tz * q[3], txx = tx * q[0], txy = ty * q[0], txz = tz * q[0], tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  const float R[9] = {1.f - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.f - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.f - (txx + tyy)};
+  for (int i = 0; i < 16; i++) T[i] = base[i];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T[i * 4 + j] = (R[i * 3] * base[j] + R[i * 3 + 1] * base[4 + j]) + R[i * 3 + 2] * base[8 + j];
+    T[i * 4 + 3] = base[i * 4 + 3] + (float)x[i];
+  }
+}
+
+// computeRDerivative (:125-176): g[3..5] = <dR/dphi, R>, <dR/dtheta, R>, <dR/dpsi, R>  (R row-major)
+void bfgs_r_derivative(const double* x, const double* R, double* g) {
+  const double cf = cos(x[3]), sf = sin(x[3]), ct = cos(x[4]), st = sin(x[4]), cp = cos(x[5]), sp = sin(x[5]);
+  const double d[3][9] = {{0., sf * sp + cf * cp * st, cf * sp - cp * sf * st, 0., -cp * sf + cf * sp * st, -cf * cp - sf * sp * st, 0., cf * ct, -ct * sf},
+                          {-cp * st, cp * ct * sf, cf * cp * ct, -sp * st, ct * sf * sp, cf * ct * sp, -ct, -sf * st, -cf * st},
+                          {-ct * sp, -cf * cp - sf * sp * st, cp * sf - cf * sp * st, cp * ct, -cf * sp + cp * sf * st, sf * sp + cf * cp * st, 0., 0., 0.}};
+  for (int k = 0; k < 3; k++) {
+    double r = 0.;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) r += d[k][j * 3 + i] * R[i * 3 + j];   // matricesInnerProd (gicp_omp.h:325-334)
+    g[3 + k] = r;
+  }
+}
+
+}  // namespace
+
+int pcm_gicp_bfgs_set_correspondences(pcm_ctx* c, const void* src, size_t n_src, const void* tgt, size_t n_tgt, size_t stride, const int32_t* idx_src, const int32_t* idx_tgt,
+                                      size_t m, const float* maha, int memory) {
+  CHECK_CTX(c);
+  if (m && (!src || !tgt || !idx_src || !idx_tgt || !maha)) return PCM_ERR_INVALID_ARGUMENT;
+  if (stride < 12 || (stride % 4) != 0) { c->err = "bad record layout"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (m > 0xffffffffull) { c->err = "too many correspondences"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (memory == PCM_MEM_HOST)
+    for (size_t i = 0; i < m; i++)
+      if (idx_src[i] < 0 || (size_t)idx_src[i] >= n_src || idx_tgt[i] < 0 || (size_t)idx_tgt[i] >= n_tgt) { c->err = "correspondence index out of range"; return PCM_ERR_INVALID_ARGUMENT; }
+  HIPCK(c, hipSetDevice(c->device));
+  c->bfgs_m = 0;
+  const size_t need = gicp_bfgs_scratch_bytes(m);
+  if (c->bfgs_cap < need) {
+    if (c->bfgs) hipFree(c->bfgs);
+    c->bfgs = nullptr; c->bfgs_cap = 0;
+    HIPCK(c, hipMalloc(&c->bfgs, need + need / 4));
+    c->bfgs_cap = need + need / 4;
+  }
+  if (m == 0) return PCM_OK;
+  const void *d_src = src, *d_tgt = tgt;
+  const int32_t *d_is = idx_src, *d_it = idx_tgt;
+  const float* d_maha = maha;
+  char* tmp = nullptr;
+  if (memory == PCM_MEM_HOST) {   // staged once per correspondence set; the evaluations then read the packed records only
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t b_src = up(n_src * stride), b_tgt = up(n_tgt * stride), b_idx = up(m * 4), b_maha = up(n_src * 64);
+    HIPCK(c, hipMallocAsync(reinterpret_cast<void**>(&tmp), b_src + b_tgt + 2 * b_idx + b_maha, c->stream));
+    char* q = tmp;
+    HIPCK(c, hipMemcpyAsync(q, src, n_src * stride, hipMemcpyHostToDevice, c->stream)); d_src = q; q += b_src;
+    HIPCK(c, hipMemcpyAsync(q, tgt, n_tgt * stride, hipMemcpyHostToDevice, c->stream)); d_tgt = q; q += b_tgt;
+    HIPCK(c, hipMemcpyAsync(q, idx_src, m * 4, hipMemcpyHostToDevice, c->stream)); d_is = reinterpret_cast<const int32_t*>(q); q += b_idx;
+    HIPCK(c, hipMemcpyAsync(q, idx_tgt, m * 4, hipMemcpyHostToDevice, c->stream)); d_it = reinterpret_cast<const int32_t*>(q); q += b_idx;
+    HIPCK(c, hipMemcpyAsync(q, maha, n_src * 64, hipMemcpyHostToDevice, c->stream)); d_maha = reinterpret_cast<const float*>(q);
+  }
+  const int rc = gicp_bfgs_pack_device(c->stream, d_src, d_tgt, stride, d_is, d_it, d_maha, m, c->bfgs, &c->err);
+  if (tmp) HIPCK(c, hipFreeAsync(tmp, c->stream));
+  if (rc != PCM_OK) return rc;
+  HIPCK(c, hipStreamSynchronize(c->stream));   // the caller's buffers are free again
+  c->bfgs_m = m;
+  return PCM_OK;
+}
+
+int pcm_gicp_bfgs_fdf(pcm_ctx* c, const float* base_T, const double* x, int mode, double* f, double* g) {
+  CHECK_CTX(c);
+  if (!base_T || !x || mode < 0 || mode > 2 || (mode != 1 && !f) || (mode != 0 && !g)) return PCM_ERR_INVALID_ARGUMENT;
+  if (c->bfgs_m == 0) { c->err = "no correspondences (pcm_gicp_bfgs_set_correspondences)"; return PCM_ERR_NO_INPUT; }
+  HIPCK(c, hipSetDevice(c->device));
+  float T[16];
+  bfgs_apply_state(base_T, x, T);
+  const size_t m = c->bfgs_m;
+  double* d_partials = reinterpret_cast<double*>(c->bfgs + ((64 * m + 255) & ~(size_t)255));
+  double* d_sums = d_partials + 14 * 1024;
+  const int rc = gicp_bfgs_fdf_device(c->stream, c->bfgs, m, T, base_T, d_partials, d_sums, &c->err);
+  if (rc != PCM_OK) return rc;
+  double s[14];
+  HIPCK(c, hipMemcpyAsync(s, d_sums, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  const double dm = (double)m;
+  if (f && mode != 1) *f = (mode == 0 ? s[0] : s[1]) / dm;
+  if (g && mode != 0) {
+    double R[9];
+    for (int a = 0; a < 3; a++) g[a] = s[2 + a] * (2.0 / dm);
+    for (int a = 0; a < 9; a++) R[a] = s[5 + a] * (2.0 / dm);
+    bfgs_r_derivative(x, R, g);
+  }
   return PCM_OK;
 }
 

@@ -80,6 +80,11 @@ int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, c
 int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride, size_t time_off, const pcm_imu_pose* d_poses, int npose, const LioStateD& s, std::string* err);
 size_t voxel_downsample_scratch_bytes(size_t n);
 int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, void* scratch, std::string* err);
+// gicp_bfgs.hip
+size_t gicp_bfgs_scratch_bytes(size_t m);
+int gicp_bfgs_pack_device(hipStream_t stream, const void* d_src, const void* d_tgt, size_t stride, const int* d_idx_src, const int* d_idx_tgt, const float* d_maha, size_t m,
+                          void* d_records, std::string* err);
+int gicp_bfgs_fdf_device(hipStream_t stream, const void* d_records, size_t m, const float T[16], const float base[16], double* d_partials, double* d_sums, std::string* err);
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
                          SortScratch* ws, std::string* err);
 
@@ -159,5 +164,7 @@ struct pcm_ctx {
   void* ws = nullptr;   // batch workspace owned by this context (pcm_api.hip)
   char* pre_arena = nullptr;   // grow-only device scratch of the pre-processing operators
   size_t pre_arena_cap = 0;
+  char* bfgs = nullptr;        // GICP-BFGS functor: packed correspondence records + partial sums (gicp_bfgs.hip)
+  size_t bfgs_cap = 0, bfgs_m = 0;
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };

@@ -229,6 +229,26 @@ class Registration:
                                                  out.ctypes.data, out.shape[0], C.byref(m)))
         return out[:m.value].copy()
 
+    def gicp_bfgs_set_correspondences(self, src, tgt, idx_src, idx_tgt, mahalanobis):
+        """Pack the correspondence set of one outer GICP-BFGS iteration (pclomp gicp_omp_impl.hpp:199-203): src/tgt (N,F) float32
+        clouds (x y z first), index pairs, mahalanobis_ as (N_src,16) float32 (column-major Matrix4f per source point)."""
+        src = np.ascontiguousarray(src, np.float32); tgt = np.ascontiguousarray(tgt, np.float32)
+        if src.ndim != 2 or tgt.ndim != 2 or src.shape[1] != tgt.shape[1] or src.shape[1] < 3:
+            raise ValueError("src/tgt: (N,F>=3) float32 with equal record sizes")
+        idx_src = np.ascontiguousarray(idx_src, np.int32); idx_tgt = np.ascontiguousarray(idx_tgt, np.int32)
+        maha = np.ascontiguousarray(mahalanobis, np.float32).reshape(-1, 16)
+        if len(idx_src) != len(idx_tgt) or maha.shape[0] != src.shape[0]:
+            raise ValueError("one index pair per correspondence, one Mahalanobis matrix per source point")
+        self._check(self._L.pcm_gicp_bfgs_set_correspondences(self._h, src.ctypes.data, src.shape[0], tgt.ctypes.data, tgt.shape[0], src.strides[0],
+                                                               idx_src.ctypes.data, idx_tgt.ctypes.data, len(idx_src), maha.ctypes.data, capi.MEM_HOST))
+
+    def gicp_bfgs_fdf(self, base_T, x, mode: int = 2):
+        """(f, g) of pclomp's OptimizationFunctorWithIndices at x (gicp_omp_impl.hpp:246-365); mode 0 = operator(), 1 = df, 2 = fdf."""
+        base = np.ascontiguousarray(base_T, np.float32).reshape(16); xx = np.ascontiguousarray(x, np.float64).reshape(6)
+        f = C.c_double(float("nan")); g = np.full(6, np.nan)
+        self._check(self._L.pcm_gicp_bfgs_fdf(self._h, base.ctypes.data, xx.ctypes.data, int(mode), C.byref(f), g.ctypes.data))
+        return f.value, g
+
     def get_target(self) -> np.ndarray:
         """(M,3) current target points in insertion order."""
         n = C.c_size_t()
