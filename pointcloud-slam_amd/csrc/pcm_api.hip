@@ -1010,7 +1010,7 @@ int pcm_gicp_bfgs_fdf(pcm_ctx* c, const float* base_T, const double* x, int mode
   bfgs_apply_state(base_T, x, T);
   const size_t m = c->bfgs_m;
   double* d_partials = reinterpret_cast<double*>(c->bfgs + ((64 * m + 255) & ~(size_t)255));
-  double* d_sums = d_partials + 14 * 1024;
+  double* d_sums = d_partials + 14 * kGicpBfgsMaxBlocks;
   const int rc = gicp_bfgs_fdf_device(c->stream, c->bfgs, m, T, base_T, d_partials, d_sums, &c->err);
   if (rc != PCM_OK) return rc;
   double s[14];

@@ -81,6 +81,7 @@ int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride
 size_t voxel_downsample_scratch_bytes(size_t n);
 int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, void* scratch, std::string* err);
 // gicp_bfgs.hip
+constexpr int kGicpBfgsMaxBlocks = 512;   // rows of the partial-sum table
 size_t gicp_bfgs_scratch_bytes(size_t m);
 int gicp_bfgs_pack_device(hipStream_t stream, const void* d_src, const void* d_tgt, size_t stride, const int* d_idx_src, const int* d_idx_tgt, const float* d_maha, size_t m,
                           void* d_records, std::string* err);
