@@ -263,7 +263,6 @@ int prepare(pcm_ctx* c) {
       if (c->cfg.model == PCM_MODEL_VGICP) {
         if (c->vvox_cap < c->map.num_voxels) {
           if (c->vvox) hipFree(c->vvox);
-    if (c->cvox) hipFree(c->cvox);
           c->vvox = nullptr; c->vvox_cap = 0;
           HIPCK(c, hipMalloc(&c->vvox, sizeof(VgVoxel) * (size_t)c->map.num_voxels));
           c->vvox_cap = c->map.num_voxels;
