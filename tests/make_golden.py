@@ -57,8 +57,23 @@ def model_case(name, model, optimizer, kw, dense):
                 cost=r.cost, H=np.array(r.H[:]).reshape(6, 6))
 
 
+def gicp_bfgs_case():
+    """pclomp GICP-BFGS functor (oracle/orc_gicp_bfgs.c): a small correspondence set with its inputs, f and g in the three modes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gicp_bfgs import _problem
+    from oracle import loader as L
+    src, tgt, isrc, itgt, maha, base, x = _problem(21, n=400, m=300, stride=4, base_translation=True)
+    out = dict(src=src, tgt=tgt, idx_src=isrc, idx_tgt=itgt, maha=maha, base=base, x=x, T=L.gicp_bfgs_apply_state(base, x))
+    for mode in (0, 1, 2):
+        f, g = L.gicp_bfgs_fdf(src, tgt, isrc, itgt, maha, base, x, mode)
+        out["f%d" % mode] = f
+        out["g%d" % mode] = g
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "gicp_bfgs_functor.npz"), **gicp_bfgs_case())
     cases = {}
     for seed in (0, 1, 2):           # three seeds of BASELINE config 1 (10k-pt scan vs 100k-pt submap)
         for opt in ("GN", "LM"):

@@ -105,3 +105,32 @@ def test_gpu_functor_argument_errors(pcm):
         g.gicp_bfgs_fdf(base, x, 5)
     f, gr = g.gicp_bfgs_fdf(base, x, 2)
     assert np.isfinite(f) and np.isfinite(gr).all()
+
+
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "gicp_bfgs_functor.npz")
+
+
+def test_oracle_reproduces_the_committed_functor_vectors():
+    """tests/golden/gicp_bfgs_functor.npz (tests/make_golden.py: oracle outputs, not reference outputs)."""
+    from oracle import loader as L
+    d = np.load(GOLD)
+    assert np.array_equal(L.gicp_bfgs_apply_state(d["base"], d["x"]), d["T"])
+    for mode in (0, 1, 2):
+        f, g = L.gicp_bfgs_fdf(d["src"], d["tgt"], d["idx_src"], d["idx_tgt"], d["maha"], d["base"], d["x"], mode)
+        if mode != 1:
+            assert f == float(d["f%d" % mode])
+        if mode != 0:
+            assert np.array_equal(g, d["g%d" % mode])
+
+
+@pytest.mark.gpu
+def test_gpu_functor_matches_the_committed_vectors(pcm):
+    d = np.load(GOLD)
+    g = pcm.GicpRegistration(0)
+    g.gicp_bfgs_set_correspondences(d["src"], d["tgt"], d["idx_src"], d["idx_tgt"], d["maha"])
+    for mode in (0, 2):
+        f, _ = g.gicp_bfgs_fdf(d["base"], d["x"], mode)
+        assert abs(f - float(d["f%d" % mode])) <= 1e-12 * abs(float(d["f%d" % mode]))
+    for mode in (1, 2):
+        _, gr = g.gicp_bfgs_fdf(d["base"], d["x"], mode)
+        assert np.abs(gr - d["g%d" % mode]).max() <= 1e-11 * np.abs(d["g%d" % mode]).max()
