@@ -123,7 +123,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # backend "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl")   # backend "nccl" is RCCL on ROCm; communicators are created by the warm-up collectives below
         else:
             dist.init_process_group("gloo")
 
@@ -153,6 +153,11 @@ def main():
     S = len(groups)
     pgs = [dist.new_group(list(range(world))) for _ in range(S)] if world > 1 else [None] * S   # one RCCL communicator per pipeline slot
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    bar_kw = {"device_ids": [dev_index]} if (world > 1 and args.backend == "nccl") else {}
+    if world > 1:   # create every communicator here, one after the other, before the slot threads use them concurrently
+        for pg in [None] + pgs:
+            dist.all_reduce(torch.zeros(1, device=dev), group=pg)
+        torch.cuda.synchronize()
 
     def sub_step(j):
         """One pass of the hot path over sub-batch j."""
@@ -200,7 +205,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(**bar_kw)
             torch.cuda.synchronize()
 
     # cold pass: includes voxel-hash build + scan re-ordering (lazy on first align)
@@ -299,7 +304,7 @@ def main():
         # the CPU leg is timed on rank 0 of the single-GPU run only (the other ranks would idle behind it)
         out["cpu_baseline"] = cpu_baseline(pairs, cfg, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
     if world > 1:
-        dist.barrier()
+        dist.barrier(**bar_kw)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
