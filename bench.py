@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--sort-source", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--stagger", type=float, default=0.5, help="start offset between the pipeline slots, in units of one warm pass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured path); gloo only to rehearse the N>1 control flow with several ranks sharing one GPU")
     args = ap.parse_args()
@@ -226,7 +227,7 @@ def main():
         regs[groups[j][0]].set_profiling(1)         # HIP events around every residual launch, on the launch stream
     fence()
     t0 = time.perf_counter()
-    res = run_steps(args.steps, stagger_s=t_warm / S if S > 1 else 0.0)
+    res = run_steps(args.steps, stagger_s=args.stagger * t_warm if S > 1 else 0.0)
     fence()
     elapsed = time.perf_counter() - t0
     sts = [regs[groups[j][0]].stats() for j in range(S)]
