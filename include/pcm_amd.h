@@ -61,7 +61,9 @@ typedef enum pcm_optimizer { PCM_OPT_GAUSS_NEWTON = 0, PCM_OPT_LEVENBERG_MARQUAR
 
 /* RegularizationMethod  include/fast_gicp/gicp/gicp_settings.hpp:6 */
 typedef enum pcm_regularization {
-  PCM_REG_NONE = 0, PCM_REG_MIN_EIG = 1, PCM_REG_NORMALIZED_MIN_EIG = 2, PCM_REG_PLANE = 3, PCM_REG_FROBENIUS = 4
+  PCM_REG_NONE = 0, PCM_REG_MIN_EIG = 1, PCM_REG_NORMALIZED_MIN_EIG = 2, PCM_REG_PLANE = 3, PCM_REG_FROBENIUS = 4,
+  PCM_REG_PCLOMP = 5   /* pclomp::GeneralizedIterativeClosestPoint::computeCovariances (ndt_omp/include/pclomp/gicp_omp_impl.hpp:48-122):
+                        * raw second moments with float products, singular values -> (1, 1, gicp_epsilon_ = 0.001) */
 } pcm_regularization;
 
 /* where a point buffer lives */

@@ -12,7 +12,7 @@ _LIB = None
 
 MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5, "VGICP_CUDA": 6}
 OPT = {"GN": 0, "LM": 1}
-REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
+REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4, "PCLOMP": 5}
 
 
 class OracleConfig(C.Structure):

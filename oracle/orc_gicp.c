@@ -135,6 +135,32 @@ void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs /* 9
     float d2[64];
     const int m = grid_knn(&g, c, c->xyz + 3 * i, k, 1e300, idx, d2);
     double mean[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (o->cfg.regularization == ORC_REG_PCLOMP) {
+      /* pclomp computeCovariances (ndt_omp/include/pclomp/gicp_omp_impl.hpp:48-122): raw second moments with FLOAT products
+       * added to doubles (nearest neighbour first), cov = S / k - mean mean^T on the lower triangle, mirrored; then the
+       * singular values are replaced by (1, 1, gicp_epsilon_ = 0.001): cov = sum_k v_k u_k u_k^T, largest first.
+       * (JacobiSVD is restated by the symmetric eigen-decomposition: U's columns are the eigenvectors, descending.) */
+      for (int j = 0; j < m; j++) {
+        const float *pt = c->xyz + 3 * (long)idx[j];
+        for (int a = 0; a < 3; a++) {
+          mean[a] += (double)pt[a];
+          for (int b = 0; b <= a; b++) cov[a * 3 + b] += (double)(pt[a] * pt[b]);
+        }
+      }
+      for (int a = 0; a < 3; a++) mean[a] /= (double)k;
+      for (int a = 0; a < 3; a++) for (int b = 0; b <= a; b++) {
+        cov[a * 3 + b] /= (double)k;
+        cov[a * 3 + b] -= mean[a] * mean[b];
+        cov[b * 3 + a] = cov[a * 3 + b];
+      }
+      double w[3], V[9], *out = covs + 9 * i;
+      orc_eig3_sym(cov, w, V);   /* ascending */
+      const double val[3] = {1.0, 1.0, 0.001};
+      for (int a = 0; a < 9; a++) out[a] = 0.0;
+      for (int kk = 0; kk < 3; kk++)
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) out[a * 3 + b] += (val[kk] * V[a * 3 + (2 - kk)]) * V[b * 3 + (2 - kk)];
+      continue;
+    }
     for (int j = 0; j < m; j++) for (int a = 0; a < 3; a++) mean[a] += (double)c->xyz[3 * (long)idx[j] + a];
     for (int a = 0; a < 3; a++) mean[a] /= (double)k;              /* rowwise().mean() over k columns */
     for (int j = 0; j < m; j++) {

@@ -24,7 +24,8 @@ extern "C" {
 
 enum { ORC_MODEL_P2PLANE = 0, ORC_MODEL_GICP = 1, ORC_MODEL_VGICP = 2, ORC_MODEL_NDT_P2D = 3, ORC_MODEL_NDT_D2D = 4, ORC_MODEL_NDT_OMP = 5, ORC_MODEL_VGICP_CUDA = 6 };
 enum { ORC_OPT_GN = 0, ORC_OPT_LM = 1 };
-enum { ORC_REG_NONE = 0, ORC_REG_MIN_EIG = 1, ORC_REG_NORMALIZED_MIN_EIG = 2, ORC_REG_PLANE = 3, ORC_REG_FROBENIUS = 4 };
+enum { ORC_REG_NONE = 0, ORC_REG_MIN_EIG = 1, ORC_REG_NORMALIZED_MIN_EIG = 2, ORC_REG_PLANE = 3, ORC_REG_FROBENIUS = 4,
+       ORC_REG_PCLOMP = 5 /* pclomp::GeneralizedIterativeClosestPoint::computeCovariances (gicp_omp_impl.hpp:48-122) */ };
 
 typedef struct orc_config {
   int model;

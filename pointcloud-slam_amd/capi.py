@@ -22,7 +22,7 @@ PCM_ERR_NOT_CONVERGED = -6
 MEM_HOST, MEM_DEVICE = 0, 1
 MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5, "VGICP_CUDA": 6}
 OPTIMIZER = {"GN": 0, "LM": 1}
-REGULARIZATION = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
+REGULARIZATION = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4, "PCLOMP": 5}
 
 
 class PcmError(RuntimeError):

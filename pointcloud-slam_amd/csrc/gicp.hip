@@ -457,8 +457,51 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
     for (int a = 0; a < 9; a++) gstore_f(of + a, cf[a]);
     return;
   }
-  // neighbours (k columns; the mean and the covariance divide by k)  fast_gicp_impl.hpp:254-260
   double mean[3] = {0.0, 0.0, 0.0}, cov[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (reg == PCM_REG_PCLOMP) {
+    // pclomp computeCovariances (gicp_omp_impl.hpp:48-122): raw second moments, FLOAT products added to doubles nearest
+    // first, cov = S / k - mean mean^T on the lower triangle (mirrored), singular values -> (1, 1, 0.001), largest first
+#pragma unroll
+    for (int j = 0; j < KCAP; j++) {
+      if (j >= KCAP - k && bi[j] != ~0u) {
+        const float4 c = gload4(tg.pts + bi[j]);
+        const float x[3] = {c.x, c.y, c.z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          mean[a] += (double)x[a];
+#pragma unroll
+          for (int b = 0; b <= a; b++) cov[a * 3 + b] += (double)(x[a] * x[b]);
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) mean[a] /= (double)k;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int b = 0; b <= a; b++) {
+        cov[a * 3 + b] /= (double)k;
+        cov[a * 3 + b] -= mean[a] * mean[b];
+        cov[b * 3 + a] = cov[a * 3 + b];
+      }
+    }
+    double w[3], V[9], R[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    eig3_sym_jacobi(cov, w, V);   // ascending
+    const double val[3] = {1.0, 1.0, 0.001};
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) R[a * 3 + b] += (val[kk] * V[a * 3 + (2 - kk)]) * V[b * 3 + (2 - kk)];
+      }
+    }
+    double* o = out + (size_t)i * 6;
+    gstore_d(o + 0, R[0]); gstore_d(o + 1, R[1]); gstore_d(o + 2, R[2]);
+    gstore_d(o + 3, R[4]); gstore_d(o + 4, R[5]); gstore_d(o + 5, R[8]);
+    return;
+  }
+  // neighbours (k columns; the mean and the covariance divide by k)  fast_gicp_impl.hpp:254-260
 #pragma unroll
   for (int j = 0; j < KCAP; j++) {
     if (j >= KCAP - k && bi[j] != ~0u) {

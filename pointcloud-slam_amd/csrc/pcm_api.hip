@@ -135,7 +135,7 @@ int validate_config(pcm_ctx* c, const pcm_config& g) {
   }
   if (is_gicp(g.model)) {
     if (g.k_correspondences < 1 || g.k_correspondences > 64) { c->err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
-    if (g.regularization < PCM_REG_NONE || g.regularization > PCM_REG_FROBENIUS) { c->err = "bad regularization method"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (g.regularization < PCM_REG_NONE || g.regularization > PCM_REG_PCLOMP || (g.regularization == PCM_REG_PCLOMP && g.model == PCM_MODEL_VGICP_CUDA)) { c->err = "bad regularization method"; return PCM_ERR_INVALID_ARGUMENT; }
     if (!(g.max_corr_dist > 0.f)) { c->err = "max_corr_dist must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
     if (g.voxel_mode < 0 || g.voxel_mode > 2) { c->err = "voxel_mode must be 0 (ADDITIVE), 1 (ADDITIVE_WEIGHTED) or 2 (MULTIPLICATIVE)"; return PCM_ERR_INVALID_ARGUMENT; }
   }

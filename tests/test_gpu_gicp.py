@@ -25,7 +25,7 @@ def _both(pcm, model, optimizer, p, **kw):
     return o, g
 
 
-@pytest.mark.parametrize("reg", ["PLANE", "MIN_EIG", "NORMALIZED_MIN_EIG", "FROBENIUS", "NONE"])
+@pytest.mark.parametrize("reg", ["PLANE", "MIN_EIG", "NORMALIZED_MIN_EIG", "FROBENIUS", "NONE", "PCLOMP"])
 def test_covariances_match_oracle(pcm, pair, reg):
     """calculate_covariances (fast_gicp_impl.hpp:239-298): exact 20-NN + regularisation, input order."""
     o, g = _both(pcm, "GICP", "LM", pair, regularization=reg)

@@ -364,3 +364,21 @@ def test_pclndt_oracle_align(synth):
     e0, _ = pose_error(p.guess, p.T_gt)
     e1, _ = pose_error(result_T(r), p.T_gt)
     assert e1 < e0          # epsilon 0.1 m: the reference stops as soon as a step is shorter than 10 cm
+
+
+def test_pclomp_covariances(synth):
+    """ORC_REG_PCLOMP (pclomp computeCovariances, gicp_omp_impl.hpp:48-122): eigenvalues (0.001, 1, 1); the same 20 neighbours as
+    the fast_gicp path, so the small axis agrees with PLANE up to the cancellation of the raw float second moments."""
+    from oracle import Oracle
+    p = synth.make_pair(6, 1500, 15000)
+    covs = {}
+    for reg in ("PLANE", "PCLOMP"):
+        o = Oracle("GICP", "LM", voxel_resolution=0.5, regularization=reg)
+        o.set_input_target(p.submap); o.set_input_source(p.scan)
+        covs[reg] = o.covariances(target=True)
+    w, V = np.linalg.eigh(covs["PCLOMP"])
+    assert np.allclose(w, [1e-3, 1.0, 1.0], rtol=1e-9)
+    _, Vp = np.linalg.eigh(covs["PLANE"])
+    cosang = np.abs(np.einsum("ia,ia->i", V[:, :, 0], Vp[:, :, 0]))
+    assert np.median(cosang) > 0.9999 and (cosang > 0.99).mean() > 0.95
+    assert np.allclose(covs["PCLOMP"], covs["PCLOMP"].transpose(0, 2, 1), atol=1e-15)
