@@ -781,6 +781,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->pleaf) hipFree(c->pleaf);
     if (c->pre_arena) hipFree(c->pre_arena);
     if (c->bfgs) hipFree(c->bfgs);
+    if (c->bfgs_host) hipHostFree(c->bfgs_host);
     if (c->ndt_partials) hipFree(c->ndt_partials);
     if (c->ndt_out) hipFree(c->ndt_out);
     if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
@@ -1009,12 +1010,11 @@ int pcm_gicp_bfgs_fdf(pcm_ctx* c, const float* base_T, const double* x, int mode
   bfgs_apply_state(base_T, x, T);
   const size_t m = c->bfgs_m;
   double* d_partials = reinterpret_cast<double*>(c->bfgs + ((64 * m + 255) & ~(size_t)255));
-  double* d_sums = d_partials + 14 * kGicpBfgsMaxBlocks;
-  const int rc = gicp_bfgs_fdf_device(c->stream, c->bfgs, m, T, base_T, d_partials, d_sums, &c->err);
+  if (!c->bfgs_host) HIPCK(c, hipHostMalloc(reinterpret_cast<void**>(&c->bfgs_host), 16 * sizeof(double), hipHostMallocDefault));
+  const int rc = gicp_bfgs_fdf_device(c->stream, c->bfgs, m, T, base_T, d_partials, c->bfgs_host, &c->err);   // the finish kernel stores to host memory
   if (rc != PCM_OK) return rc;
-  double s[14];
-  HIPCK(c, hipMemcpyAsync(s, d_sums, sizeof(s), hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
+  const double* s = c->bfgs_host;
   const double dm = (double)m;
   if (f && mode != 1) *f = (mode == 0 ? s[0] : s[1]) / dm;
   if (g && mode != 0) {

@@ -167,5 +167,6 @@ struct pcm_ctx {
   size_t pre_arena_cap = 0;
   char* bfgs = nullptr;        // GICP-BFGS functor: packed correspondence records + partial sums (gicp_bfgs.hip)
   size_t bfgs_cap = 0, bfgs_m = 0;
+  double* bfgs_host = nullptr; // pinned, device-visible: the 14 sums land here without a copy command
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };
