@@ -105,8 +105,9 @@ typedef struct pcm_config {
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
-#define PCM_FLAG_FUSED_STEP 2       /* late GN rounds: take the step in the search kernel's last workgroup instead of a second launch
-                                     * (measured slower: the agent-scope release/acquire pair flushes L2 under the other stream; off by default) */
+#define PCM_FLAG_FUSED_STEP 2       /* accepted and ignored: since round 2 the GN step of the point-to-plane model is taken by the last workgroup
+                                     * of the search launch by default (write-through hand-off of the partial rows) */
+#define PCM_FLAG_SEPARATE_STEP 4    /* take the GN step in a second launch (k_finish_round) instead; same sums in the same order */
 
 /* out-parameters of align(): getFinalTransformation / hasConverged /
  * getFinalHessian / nr_iterations_  (lsq_registration_impl.hpp:40-79) */

@@ -202,24 +202,48 @@ __device__ inline void unpack_sums(const double* s, double* H, double* b, double
   *inliers = (int)s[28];
 }
 
-// The step of one pair done by the LAST workgroup of its k_linearize launch (rounds with one or two live pairs, where a
-// second launch costs more than the work): the same sums in the same order as k_finish_round (its 32 row groups are
-// walked four at a time by 256 threads), so a pair's result does not depend on which path ran its rounds.
+// Write-through (sc1) accessors of the partial rows for the in-launch hand-off below: an agent-scope relaxed atomic store /
+// load of the 8 bytes lowers to global_store_dwordx2 / global_load_dwordx2 with sc1, which writes through the XCD's L2 and
+// reads past this CU's L1 (/opt/skills/guides/MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup
+// visibility": valid forms with `sc1` stores and loads on both sides).
+__device__ inline void gstore_d_wt(double* p, double v) {
+  __hip_atomic_store((PCM_GLOBAL unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double gload_d_wt(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const PCM_GLOBAL unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// The step of one pair done by the LAST workgroup of its k_linearize launch: the same sums in the same order as
+// k_finish_round (its 32 row groups are walked four at a time by 256 threads), so a pair's result does not depend on
+// which path ran its rounds.  The rows were stored write-through by their workgroups and are read with sc1 loads.
 __device__ inline void finish_pair_in_place(const PairDesc& d, PairState* states, int pair, const LsqParams& lp, int nblocks, unsigned char* flags_row, double* s_grp /* 32 x 32 */,
                                             double* s_tot /* 32 */) {
+  // thread (g8, j) owns row groups r = g8, g8 + 8, g8 + 16, g8 + 24 of column j; the rows of a group (b = r, r + 32, ...) are
+  // added in that order exactly as k_finish_round does, but the write-through loads pay a fabric round trip each, so 16 rows
+  // of two groups are fetched at once (32 loads in flight) before the adds
   const int j = threadIdx.x & 31, g8 = threadIdx.x >> 5;
-  for (int r = g8; r < 32; r += 8) {
-    double v = 0.0;
-    if (j < kNumSums) {
-      int b = r;
-      for (; b + 96 < nblocks; b += 128) {
-        const double v0 = gload_d(d.partials + (size_t)b * kPartialStride + j), v1 = gload_d(d.partials + (size_t)(b + 32) * kPartialStride + j),
-                     v2 = gload_d(d.partials + (size_t)(b + 64) * kPartialStride + j), v3 = gload_d(d.partials + (size_t)(b + 96) * kPartialStride + j);
-        v = (((v + v0) + v1) + v2) + v3;
+  const int jj = j < kNumSums ? j : 0;
+#pragma unroll 1
+  for (int h = 0; h < 2; h++) {
+    const int r0 = g8 + 16 * h, r1 = r0 + 8;
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll 1
+    for (int base = 0; base < nblocks; base += 32 * 16) {
+      double x0[16], x1[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const int b0 = base + r0 + 32 * k, b1 = base + r1 + 32 * k;
+        x0[k] = b0 < nblocks ? gload_d_wt(d.partials + (size_t)b0 * kPartialStride + jj) : 0.0;
+        x1[k] = b1 < nblocks ? gload_d_wt(d.partials + (size_t)b1 * kPartialStride + jj) : 0.0;
       }
-      for (; b < nblocks; b += 32) v += gload_d(d.partials + (size_t)b * kPartialStride + j);
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        if (base + r0 + 32 * k < nblocks) v0 += x0[k];
+        if (base + r1 + 32 * k < nblocks) v1 += x1[k];
+      }
     }
-    s_grp[r * kPartialStride + j] = v;
+    s_grp[r0 * kPartialStride + j] = j < kNumSums ? v0 : 0.0;
+    s_grp[r1 * kPartialStride + j] = j < kNumSums ? v1 : 0.0;
   }
   __syncthreads();
   if (threadIdx.x < kNumSums) {
@@ -486,22 +510,15 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
             v[r] = gload4(tg.pts + s_bps[b] + (k - s_boff[b]));
           }
         }
-  #pragma unroll
-        for (int r = 0; r < kCapPts / 256; r++) {
-          const uint32_t k = threadIdx.x + 256u * r;
-          if (k < total) s_pts[k] = v[r];
-        }
-        if (threadIdx.x == 0) s_pts[total] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));   // end-of-run sentinel
-        __syncthreads();
-        PCM_STAMP(2)   // stage map points
-        // ---- every voxel head among the staged points registers itself in the cell grid ------------
+        // every voxel head among the staged points (bit 31 of its tag) registers itself in the cell grid while the
+        // points go to LDS: one barrier for both
   #pragma unroll
         for (int r = 0; r < kCapPts / 256; r++) {
           const uint32_t k = threadIdx.x + 256u * r;
           if (k < total) {
+            s_pts[k] = v[r];
             const int tag = __float_as_int(v[r].w);
-            const bool head = k == s_boff[vb[r]] || __float_as_int(s_pts[k - 1].w) != tag;
-            if (head) {
+            if (tag < 0) {
               const int4 o = s_borg[vb[r]];
               const int li = tag & 511;
               const int x = o.x + (li >> 6), y = o.y + ((li >> 3) & 7), z = o.z + (li & 7);
@@ -509,7 +526,9 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
             }
           }
         }
+        if (threadIdx.x == 0) s_pts[total] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));   // end-of-run sentinel (a "head")
         __syncthreads();
+        PCM_STAMP(2)   // stage map points
         PCM_STAMP(3)   // cell grid
         // ---- per-lane 27-cell / 5-NN search out of LDS (reference cell order) ----------------------
         if (search) {
@@ -524,20 +543,19 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
             kh[g] = kNoCell;
             if (g < kp.num_neighbors) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
           }
-          // a voxel's points are one run of s_pts; s_pts[total] is a sentinel whose tag matches no voxel, so the
-          // run ends on a tag change alone.  The list carries byte offsets (k * 16) until the search is over.
+          // a voxel's points are one run of s_pts that ends where the next voxel head (tag bit 31; the sentinel
+          // s_pts[total] is one) begins.  The list carries byte offsets (k * 16) until the search is over.
           const char* pbase = reinterpret_cast<const char*>(s_pts);
   #pragma unroll
           for (int g = 0; g < 27; g++) {
             if (kh[g] != kNoCell) {
               uint32_t off = (uint32_t)kh[g] << 4;
               float4 mp = *reinterpret_cast<const float4*>(pbase + off);
-              const int tag = __float_as_int(mp.w);
               for (;;) {
                 const float4 nx = *reinterpret_cast<const float4*>(pbase + off + 16);
                 if (STATS) n_cand++;
                 best_offer(best, mp, q, off, kp.max_range_sq);
-                if (__float_as_int(nx.w) != tag) break;
+                if (__float_as_int(nx.w) < 0) break;   // the next staged point opens another voxel (or is the sentinel)
                 mp = nx;
                 off += 16;
               }
@@ -731,26 +749,46 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
       s_grp[g * kPartialStride + j] = v;
     }
     __syncthreads();
-    if (threadIdx.x < kNumSums) {
-      double v = 0.0;
+    if constexpr (!FUSED) {
+      if (threadIdx.x < kNumSums) {
+        double v = 0.0;
   #pragma unroll
-      for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
-      gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
-    }
-    if constexpr (FUSED) {
-      // arrival ticket: the workgroup that completes the pair's round sums the partial rows and takes the GN step
+        for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
+        gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+      }
+    } else {
+      // In-launch hand-off of the partial rows to the workgroup that completes the pair's round (no second launch, no
+      // agent-scope release fence -- that fence writes back the whole L2 and cost more than the launch it saved):
+      //   producer  the 29 sums are stored write-through (sc1) by lanes of wave 0; the wave drains its stores
+      //             (s_waitcnt vmcnt(0)) and only then lane 0 takes the arrival ticket (agent-scope relaxed add);
+      //   consumer  the workgroup whose ticket is the last one: lane 0 runs ONE agent-scope acquire (buffer_inv sc1:
+      //             this CU's L1 / non-local L2 lines of earlier rounds) behind its returned add, the workgroup barrier
+      //             releases the other waves, and every row is read with sc1 loads.
+      // The ticket counter is reset by the last arriver; the next round is a later launch on the same stream.
       __shared__ unsigned int s_last;
-      __threadfence();                    // this workgroup's partial row is visible device-wide before its ticket
-      __syncthreads();
-      const int nblocks = (int)((d.src.num_points + 255u) / 256u);
-      if (threadIdx.x == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == (unsigned int)(nblocks - 1)) ? 1u : 0u;
-        if (s_last) __hip_atomic_store(d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next round
+      if (threadIdx.x < 64) {   // wave 0
+        if (threadIdx.x < kNumSums) {
+          double v = 0.0;
+  #pragma unroll
+          for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
+          gstore_d_wt(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+          const int nblocks = (int)((d.src.num_points + 255u) / 256u);
+          const unsigned int t = __hip_atomic_fetch_add((PCM_GLOBAL unsigned int*)d.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned int last = (t == (unsigned int)(nblocks - 1)) ? 1u : 0u;
+          if (last) {
+            __hip_atomic_store((PCM_GLOBAL unsigned int*)d.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next round's launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          s_last = last;
+        }
       }
       __syncthreads();
       if (s_last) {
-        __threadfence();                  // acquire: the other workgroups' rows
+        const int nblocks = (int)((d.src.num_points + 255u) / 256u);
         double* f_grp = reinterpret_cast<double*>(s_pts);          // 32 x 32 doubles; s_pts is free by now
         double* f_tot = f_grp + 32 * kPartialStride;
         finish_pair_in_place(d, const_cast<PairState*>(states), pair, lp, nblocks, flags_row, f_grp, f_tot);

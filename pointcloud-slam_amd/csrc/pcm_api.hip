@@ -537,8 +537,9 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     }
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
-    // optional (PCM_FLAG_FUSED_STEP): in late GN rounds (one or two pairs left) the last workgroup of a pair's launch takes its step
-    const bool fuse = use_list && !is_lm && !ndt && !gicp && !counters_on && !timing_on && nl <= 2 && kp.do_step && (g.flags & PCM_FLAG_FUSED_STEP);
+    // GN: the last workgroup of a pair's search launch takes its step (write-through hand-off of the partial rows, kernels.hip);
+    // PCM_FLAG_SEPARATE_STEP keeps the second launch (k_finish_round) for A/B runs and the bit-equality test
+    const bool fuse = use_list && !is_lm && !ndt && !gicp && !counters_on && !timing_on && kp.do_step && (g.flags & PCM_FLAG_FUSED_STEP) && !(g.flags & PCM_FLAG_SEPARATE_STEP);
     if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), false);
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);

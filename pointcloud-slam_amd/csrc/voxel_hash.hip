@@ -119,7 +119,7 @@ __global__ void k_finalize_bricks(BrickSlot* __restrict__ slots, const uint32_t*
   }
 }
 
-// points into sorted order, tagged with (brick slot << 9 | voxel-in-brick)
+// points into sorted order, tagged with (voxel-head bit << 31 | brick slot << 9 | voxel-in-brick)
 __global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ keys, uint32_t n,
                                 const BrickSlot* __restrict__ slots, uint32_t mask, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,7 +129,10 @@ __global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* _
   uint32_t h = hash_coord(bx, by, bz) & mask;
   while (slots[h].key != bkey) h = (h + 1) & mask;
   float4 p = in[idx[i]];
-  p.w = __int_as_float((int)((h << 9) | (uint32_t)(keys[i] & 511u)));
+  // bit 31 marks the first point of a voxel's run, so a reader of a staged run finds voxel heads and run ends without
+  // comparing neighbouring tags (the slot index fits bits 9..30: kMaxBrickSlots)
+  const uint32_t head = (i == 0 || keys[i - 1] != keys[i]) ? 0x80000000u : 0u;
+  p.w = __int_as_float((int)(head | (h << 9) | (uint32_t)(keys[i] & 511u)));
   out[i] = p;
 }
 
