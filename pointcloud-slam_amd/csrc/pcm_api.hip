@@ -394,6 +394,7 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.points_per_block = geom.points_per_block;
   kp.tiles_per_pair = geom.tiles_per_pair;
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
+  kp.pipe_deep = (g.flags & PCM_FLAG_PIPE_DEEP) ? 1 : 0;
   kp.do_step = 1;
   kp.lin_points_per_block = (is_ndt(g.model) || g.model == PCM_MODEL_VGICP_CUDA) ? geom.points_per_block : 256;
   kp.coord_mode = coord_mode_for(g.model);
@@ -540,8 +541,12 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     // GN: the last workgroup of a pair's search launch takes its step (write-through hand-off of the partial rows, kernels.hip);
     // PCM_FLAG_SEPARATE_STEP keeps the second launch (k_finish_round) for A/B runs and the bit-equality test
     const bool fuse = use_list && !is_lm && !ndt && !gicp && !counters_on && !timing_on && kp.do_step && (g.flags & PCM_FLAG_FUSED_STEP) && !(g.flags & PCM_FLAG_SEPARATE_STEP);
+    // PCM_FLAG_PIPE_KERNEL: the pipelined search kernel (several tiles per workgroup, next tile's loads under this tile's
+    // arithmetic; bit-identical results).  Measured SLOWER than one tile per workgroup at every depth
+    const bool pipe = use_list && !ndt && !gicp && !counters_on && !timing_on && (g.flags & PCM_FLAG_PIPE_KERNEL);
     if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), false);
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
+    else if (pipe) launch_linearize_pipe(st, w->d_descs, w->d_states, kpr, lp, nl, write_sel, fuse, w->d_flags + (size_t)r * n);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
@@ -643,6 +648,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
   if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, ndt_kind(c->cfg.model), !linearize);
   else if (is_gicp(c->cfg.model)) launch_gicp(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_VGICP, !linearize);
+  else if (linearize && (c->cfg.flags & PCM_FLAG_PIPE_KERNEL)) launch_linearize_pipe(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, true, false, w->d_flags);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
   launch_finish_round(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, !linearize, false, w->d_flags, w->d_sums);

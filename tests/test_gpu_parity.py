@@ -300,3 +300,34 @@ def test_fused_step_equals_separate_step(pcm, synth):
         r = o.align(p.guess)
         dt, dr = pose_error(result_T(r), a.T64)
         assert dt < POSE_TOL_M and dr < POSE_TOL_RAD and a.iterations == r.iterations
+
+
+@pytest.mark.gpu
+def test_pipelined_kernel_equals_one_tile_kernel(pcm, synth):
+    """The pipelined search kernel (several tiles per workgroup, next tile's loads issued under this tile's arithmetic;
+    flag 16 forces >= 4 tiles per workgroup on these small clouds) computes the same per-tile sums in the same order as the
+    default one-tile-per-workgroup kernel (the pipelined one is PCM_FLAG_PIPE_KERNEL = 8): poses, iteration counts and the normal equations of the
+    parity hook are bit-identical, with the step in a second launch or in the last workgroup (PCM_FLAG_FUSED_STEP = 2),
+    GN and LM, ragged batch, 7 / 27 cells."""
+    pairs = [synth.make_pair(60 + i, 3000 + 1700 * i, 30000 + 9000 * i) for i in range(6)]
+    guesses = np.stack([p.guess for p in pairs])
+    for opt in ("GN", "LM"):
+        for nn in (27, 7):
+            out = {}
+            for flags in (0, 8, 8 | 16, 8 | 16 | 2, 8 | 2):
+                regs = []
+                for p in pairs:
+                    g = pcm.P2PlaneRegistration(0, optimizer=opt, num_neighbors=nn, flags=flags)
+                    g.set_input_target(p.submap); g.set_input_source(p.scan); regs.append(g)
+                res = pcm.align_batch(regs, guesses)
+                lin = [regs[k].evaluate_cost(res[k].T64) for k in (0, 3)]
+                out[flags] = (res, lin)
+            ref, ref_lin = out[0]
+            for flags in (8, 8 | 16, 8 | 16 | 2, 8 | 2):
+                res, lin = out[flags]
+                for a, b in zip(ref, res):
+                    assert np.array_equal(a.T64, b.T64), (opt, nn, flags)
+                    assert a.iterations == b.iterations and a.num_inliers == b.num_inliers and a.num_linearize == b.num_linearize
+                    assert a.converged == b.converged
+                for (ca, Ha, ba, ia), (cb, Hb, bb, ib) in zip(ref_lin, lin):
+                    assert np.array_equal(Ha, Hb) and np.array_equal(ba, bb) and ca == cb and ia == ib
