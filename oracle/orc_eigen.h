@@ -179,7 +179,7 @@ static inline void orc_eig_ldlt6_solve(const double A_in[36], const double rhs[6
  * contiguous column segments [CORE-1].  Both instantiations have runtime-size segments (tail(), bottomRightCorner())
  * except the initial column norms of the fixed 5x3 float matrix, whose fixed size 5 gives the same order.
  * ============================================================================================= */
-#define ORC_EIG_QR_MAXR 8
+#define ORC_EIG_QR_MAXR 32
 #define ORC_DEF_EIG_COLPIVQR(NAME, T, SQRT, FABS, EPS, TMIN, REDUX)                                        \
   static inline void NAME(const T *A_rowmajor, int rows, const T *b_in, T x[3]) {                           \
     const int cols = 3;                                                                                     \
@@ -578,8 +578,10 @@ static inline void orc_eig_direct3f(const float A[9], float w[3], float V[9]) {
     float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
     q = q > 0.0f ? q : 0.0f;
     const float rho = sqrtf(a_over_3);
-    const float theta = atan2f(sqrtf(q), half_b) * s_inv3;
-    const float cos_theta = cosf(theta), sin_theta = sinf(theta);
+    /* atan2 / cos / sin: evaluated in double and rounded to float on both sides of the parity tests (the reference runs
+     * CUDA's device libm here, whose last-ulp behaviour no host library reproduces) */
+    const float theta = (float)atan2((double)sqrtf(q), (double)half_b) * s_inv3;
+    const float cos_theta = (float)cos((double)theta), sin_theta = (float)sin((double)theta);
     ev[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     ev[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
     ev[2] = c2_over_3 + 2.0f * rho * cos_theta;

@@ -96,27 +96,25 @@ static int grid_knn(const orc_grid *g, const orc_cloud *c, const float q[3], int
 static void regularize(int method, const double cov[9], double out[9]) {
   if (method == ORC_REG_NONE) { memcpy(out, cov, 9 * sizeof(double)); return; }
   if (method == ORC_REG_FROBENIUS) {   /* :266-271 */
-    double C[9], Ci[9], N[9];
+    double C[9], Ci[9], N[9], sq[9];
     memcpy(C, cov, sizeof(C));
     C[0] += 1e-3; C[4] += 1e-3; C[8] += 1e-3;
     orc_inv3d(C, Ci);
-    double nrm = 0.0;
-    for (int a = 0; a < 9; a++) nrm += Ci[a] * Ci[a];
-    nrm = sqrt(nrm);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sq[b * 3 + a] = Ci[a * 3 + b] * Ci[a * 3 + b];   /* Matrix3d::norm(): fixed-size sum over the column-major coefficients */
+    const double nrm = sqrt(orc_redux_fixed_d(sq, 9));
     for (int a = 0; a < 9; a++) N[a] = Ci[a] / nrm;
     orc_inv3d(N, out);
     return;
   }
-  double w[3], V[9], val[3];
-  orc_eig3_sym(cov, w, V);   /* ascending; singular values of the SVD are these, descending */
-  if (method == ORC_REG_PLANE) { val[0] = 1e-3; val[1] = 1.0; val[2] = 1.0; }                         /* (1, 1, 1e-3) on descending order */
-  else if (method == ORC_REG_MIN_EIG) { for (int k = 0; k < 3; k++) val[k] = w[k] > 1e-3 ? w[k] : 1e-3; }
-  else { for (int k = 0; k < 3; k++) { const double v = w[k] / w[2]; val[k] = v > 1e-3 ? v : 1e-3; } }   /* NORMALIZED_MIN_EIG */
-  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
-    double s = 0.0;
-    for (int k = 0; k < 3; k++) s += V[a * 3 + k] * val[k] * V[b * 3 + k];
-    out[a * 3 + b] = s;
-  }
+  /* Eigen::JacobiSVD<Matrix3d>(cov, ComputeFullU | ComputeFullV)  :273, restated from Eigen/src/SVD/JacobiSVD.h (orc_eigen.h) */
+  double U[9], S[3], V[9], val[3];
+  orc_eig_jacobi_svd(3, cov, U, S, V);
+  if (method == ORC_REG_PLANE) { val[0] = 1.0; val[1] = 1.0; val[2] = 1e-3; }                          /* :280 */
+  else if (method == ORC_REG_MIN_EIG) { for (int k = 0; k < 3; k++) val[k] = S[k] > 1e-3 ? S[k] : 1e-3; }   /* :283 */
+  else { for (int k = 0; k < 3; k++) { const double v = S[k] / S[0]; val[k] = v > 1e-3 ? v : 1e-3; } }      /* :286-287 NORMALIZED_MIN_EIG (maxCoeff = S[0]) */
+  /* svd.matrixU() * values.asDiagonal() * svd.matrixV().transpose()  :292 */
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++)
+    out[a * 3 + b] = ((U[a * 3 + 0] * val[0]) * V[b * 3 + 0] + (U[a * 3 + 1] * val[1]) * V[b * 3 + 1]) + (U[a * 3 + 2] * val[2]) * V[b * 3 + 2];
 }
 
 void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs /* 9 per point */) {
@@ -138,8 +136,7 @@ void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs /* 9
     if (o->cfg.regularization == ORC_REG_PCLOMP) {
       /* pclomp computeCovariances (ndt_omp/include/pclomp/gicp_omp_impl.hpp:48-122): raw second moments with FLOAT products
        * added to doubles (nearest neighbour first), cov = S / k - mean mean^T on the lower triangle, mirrored; then the
-       * singular values are replaced by (1, 1, gicp_epsilon_ = 0.001): cov = sum_k v_k u_k u_k^T, largest first.
-       * (JacobiSVD is restated by the symmetric eigen-decomposition: U's columns are the eigenvectors, descending.) */
+       * singular values are replaced by (1, 1, gicp_epsilon_ = 0.001): cov = sum_k v_k u_k u_k^T, largest first. */
       for (int j = 0; j < m; j++) {
         const float *pt = c->xyz + 3 * (long)idx[j];
         for (int a = 0; a < 3; a++) {
@@ -153,12 +150,12 @@ void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs /* 9
         cov[a * 3 + b] -= mean[a] * mean[b];
         cov[b * 3 + a] = cov[a * 3 + b];
       }
-      double w[3], V[9], *out = covs + 9 * i;
-      orc_eig3_sym(cov, w, V);   /* ascending */
+      double U[9], S[3], *out = covs + 9 * i;
+      orc_eig_jacobi_svd(3, cov, U, S, NULL);   /* JacobiSVD<Matrix3d>(cov, ComputeFullU)  gicp_omp_impl.hpp:110 */
       const double val[3] = {1.0, 1.0, 0.001};
       for (int a = 0; a < 9; a++) out[a] = 0.0;
-      for (int kk = 0; kk < 3; kk++)
-        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) out[a * 3 + b] += (val[kk] * V[a * 3 + (2 - kk)]) * V[b * 3 + (2 - kk)];
+      for (int kk = 0; kk < 3; kk++)      /* cov += v * col * col.transpose()  :114-120 */
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) out[a * 3 + b] += (val[kk] * U[a * 3 + kk]) * U[b * 3 + kk];
       continue;
     }
     for (int j = 0; j < m; j++) for (int a = 0; a < 3; a++) mean[a] += (double)c->xyz[3 * (long)idx[j] + a];
@@ -179,7 +176,7 @@ void orc_calc_covariances(const oracle *o, const orc_cloud *c, double *covs /* 9
  * covariance_regularization.cu:14-121 (PLANE: V diag(1e-3, 1, 1) V^-1 with the eigenvectors of the self-adjoint solver,
  * MIN_EIG, FROBENIUS; the other methods are "unimplemented" there and leave the covariance as it is).
  * Neighbours: the CPU kd-tree of FastVGICPCuda (fast_vgicp_cuda_impl.hpp:97-101,152-170), k nearest incl. the point itself.
- * Eigen's float computeDirect is replaced by the cyclic Jacobi in double, cast to float (same stand-in as the NDT voxels). */
+ * computeDirect is the closed-form float solver of Eigen/src/Eigenvalues/SelfAdjointEigenSolver.h:577-733 (orc_eigen.h). */
 static void regularize_f(int method, float c[9]) {
   if (method == ORC_REG_FROBENIUS) {
     float C[9], Ci[9], N[9];
@@ -194,14 +191,12 @@ static void regularize_f(int method, float c[9]) {
     return;
   }
   if (method != ORC_REG_PLANE && method != ORC_REG_MIN_EIG) return;
-  double sym[9], w[3], V[9];
-  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sym[a * 3 + b] = (double)c[(a > b ? a : b) * 3 + (a > b ? b : a)];
-  orc_eig3_sym(sym, w, V);
-  float Vf[9], Vi[9], val[3], VD[9];
-  for (int a = 0; a < 9; a++) Vf[a] = (float)V[a];
-  if (method == ORC_REG_PLANE) { val[0] = 1e-3f; val[1] = 1.0f; val[2] = 1.0f; }
-  else for (int k = 0; k < 3; k++) val[k] = fmaxf(1e-3f, (float)w[k]);
-  orc_inv3f(Vf, Vi);
+  /* SelfAdjointEigenSolver<Matrix3f>::computeDirect  covariance_regularization.cu:57-58,84-85 (orc_eigen.h) */
+  float w[3], Vf[9], Vi[9], val[3], VD[9];
+  orc_eig_direct3f(c, w, Vf);
+  if (method == ORC_REG_PLANE) { val[0] = 1e-3f; val[1] = 1.0f; val[2] = 1.0f; }      /* :62 */
+  else for (int k = 0; k < 3; k++) val[k] = fmaxf(1e-3f, w[k]);                        /* :88-90 */
+  orc_inv3f(Vf, Vi);                                                                    /* eigenvectors().inverse() */
   for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) VD[a * 3 + b] = Vf[a * 3 + b] * val[b];
   for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) c[a * 3 + b] = (VD[a * 3 + 0] * Vi[0 * 3 + b] + VD[a * 3 + 1] * Vi[1 * 3 + b]) + VD[a * 3 + 2] * Vi[2 * 3 + b];
 }
@@ -349,12 +344,17 @@ static void vg_offsets(int n, int out[27][3]) {
   else for (int t = 0; t < n && t < 7; t++) memcpy(out[t], VG_DIRECT7[t], sizeof(int) * 3);
 }
 
-/* M = (cov_B + T cov_A T^T)^-1 on the 3x3 block (the reference inverts the 4x4 with (3,3) = 1)  fast_gicp_impl.hpp:146-150 */
+/* M = (cov_B + T cov_A T^T)^-1 with (3,3) forced to 1 before and 0 after: the reference inverts the 4x4 matrix
+ * (fast_gicp_impl.hpp:146-150), i.e. Eigen's Packet2d 4x4 inverse (Eigen/src/LU/arch/InverseSize4.h, orc_eig_inv4d);
+ * the 3x3 block of the result is what the cost reads. */
 static void maha3(const double CB[9], const double CA[9], const double T[16], double M[9]) {
-  double RC[9], S[9];
+  double RC[9], S4[16], I4[16];
   for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) RC[a * 3 + b] = T[a * 4 + 0] * CA[0 * 3 + b] + T[a * 4 + 1] * CA[1 * 3 + b] + T[a * 4 + 2] * CA[2 * 3 + b];
-  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S[a * 3 + b] = CB[a * 3 + b] + (RC[a * 3 + 0] * T[b * 4 + 0] + RC[a * 3 + 1] * T[b * 4 + 1] + RC[a * 3 + 2] * T[b * 4 + 2]);
-  orc_inv3d(S, M);
+  for (int a = 0; a < 16; a++) S4[a] = 0.0;
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) S4[a * 4 + b] = CB[a * 3 + b] + (RC[a * 3 + 0] * T[b * 4 + 0] + RC[a * 3 + 1] * T[b * 4 + 1] + RC[a * 3 + 2] * T[b * 4 + 2]);
+  S4[15] = 1.0;
+  orc_eig_inv4d(S4, I4);
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) M[a * 3 + b] = I4[a * 4 + b];
 }
 
 static double gicp_pass(oracle *o, const double T[16], int update, double *H, double *b) {

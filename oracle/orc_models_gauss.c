@@ -108,18 +108,17 @@ static void gmap_build(orc_gmap *m, const orc_cloud *cl, float res) {
     for (int a = 0; a < 3; a++) mean[a] = sx[v * 3 + a] / nn;
     /* voxel_covs = (sum x x^T - mean * sum x^T) / n   gaussian_voxelmap.cu:193-194 */
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) cov[a * 3 + b] = (sxx[v * 9 + a * 3 + b] - mean[a] * sx[v * 3 + b]) / nn;
-    /* symmetrise before the self-adjoint decomposition (Eigen reads the lower triangle) */
-    for (int a = 0; a < 3; a++) for (int b = a + 1; b < 3; b++) cov[a * 3 + b] = cov[b * 3 + a];
-    double w[3], V[9];
-    orc_eig3_sym(cov, w, V);
-    for (int k = 0; k < 3; k++) w[k] = w[k] > 1e-3 ? w[k] : 1e-3;   /* fmaxf(1e-3f, values[i]) */
+    /* covariance_regularization_mineig (covariance_regularization.cu:83-97) on the float voxel covariance: computeDirect
+     * (closed form, reads the lower triangle; orc_eigen.h), eigenvalues clamped at 1e-3, V diag V^-1 */
+    float cf[9], w[3], Vf[9], Vi[9], VD[9];
+    for (int a = 0; a < 9; a++) cf[a] = (float)cov[a];
+    orc_eig_direct3f(cf, w, Vf);
+    for (int k = 0; k < 3; k++) w[k] = fmaxf(1e-3f, w[k]);
+    orc_inv3f(Vf, Vi);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) VD[a * 3 + b] = Vf[a * 3 + b] * w[b];
     for (int a = 0; a < 3; a++) {
       g->mean[a] = (float)mean[a];
-      for (int b = 0; b < 3; b++) {
-        double s = 0.0;
-        for (int k = 0; k < 3; k++) s += V[a * 3 + k] * w[k] * V[b * 3 + k];
-        g->cov[a * 3 + b] = (float)s;
-      }
+      for (int b = 0; b < 3; b++) g->cov[a * 3 + b] = (VD[a * 3 + 0] * Vi[0 * 3 + b] + VD[a * 3 + 1] * Vi[1 * 3 + b]) + VD[a * 3 + 2] * Vi[2 * 3 + b];
     }
   }
   free(sx); free(sxx); free(cnt); free(pv);

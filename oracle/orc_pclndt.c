@@ -95,7 +95,7 @@ static void build_leaves(oracle *o) {
     for (int a = 0; a < 9; a++) l->cov[a] *= (l->n - 1.0) / l->n;                                                 /* :324 */
     double w[3], V[9], sym[9];
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sym[a * 3 + b] = l->cov[(a > b ? a : b) * 3 + (a > b ? b : a)];   /* self-adjoint view: lower triangle */
-    orc_eig3_sym(sym, w, V);
+    orc_eig_selfadjoint3(sym, w, V);   /* eigensolver.compute(leaf.cov_)  :327 -> Eigen/src/Eigenvalues/SelfAdjointEigenSolver.h:412-462 (orc_eigen.h) */
     if (w[0] < 0 || w[1] < 0 || w[2] <= 0) { l->n = -1; continue; }                                              /* :331-335 */
     const double min_ev = min_covar_eigvalue_mult * w[2];
     if (w[0] < min_ev) {                                                                                          /* :339-349 */
@@ -378,42 +378,9 @@ static void hessian_only(oracle *o, const float T[16], double H[36]) {
   }
 }
 
-/* ---- Eigen::JacobiSVD<Matrix6d>(H, FullU | FullV).solve(b): one-sided Jacobi ------------------ */
-static void svd_solve6(const double Hin[36], const double b[6], double x[6]) {
-  double U[36], V[36];
-  memcpy(U, Hin, sizeof(U));
-  for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; sweep++) {
-    int rotated = 0;
-    for (int p = 0; p < 5; p++) for (int q = p + 1; q < 6; q++) {
-      double al = 0, be = 0, ga = 0;
-      for (int k = 0; k < 6; k++) { al += U[k * 6 + p] * U[k * 6 + p]; be += U[k * 6 + q] * U[k * 6 + q]; ga += U[k * 6 + p] * U[k * 6 + q]; }
-      if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
-      rotated = 1;
-      const double zeta = (be - al) / (2.0 * ga);
-      const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-      const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-      for (int k = 0; k < 6; k++) {
-        const double up = U[k * 6 + p], uq = U[k * 6 + q];
-        U[k * 6 + p] = c * up - sn * uq; U[k * 6 + q] = sn * up + c * uq;
-        const double vp = V[k * 6 + p], vq = V[k * 6 + q];
-        V[k * 6 + p] = c * vp - sn * vq; V[k * 6 + q] = sn * vp + c * vq;
-      }
-    }
-    if (!rotated) break;
-  }
-  double sig[6], smax = 0.0;
-  for (int j = 0; j < 6; j++) { double n2 = 0; for (int k = 0; k < 6; k++) n2 += U[k * 6 + j] * U[k * 6 + j]; sig[j] = sqrt(n2); if (sig[j] > smax) smax = sig[j]; }
-  double thr = smax * 6.0 * DBL_EPSILON;                   /* SVDBase::threshold(): diagSize * epsilon, premultiplied by sigma_max */
-  if (thr < DBL_MIN) thr = DBL_MIN;
-  for (int i = 0; i < 6; i++) x[i] = 0.0;
-  for (int j = 0; j < 6; j++) {
-    if (!(sig[j] > thr)) continue;
-    double ub = 0;
-    for (int k = 0; k < 6; k++) ub += (U[k * 6 + j] / sig[j]) * b[k];
-    for (int i = 0; i < 6; i++) x[i] += V[i * 6 + j] * (ub / sig[j]);
-  }
-}
+/* ---- Eigen::JacobiSVD<Matrix6d>(H, FullU | FullV).solve(b)  :112-114: two-sided Jacobi of Eigen/src/SVD/JacobiSVD.h
+ *      and SVDBase::_solve_impl, restated in orc_eigen.h ---------------------------------------- */
+static void svd_solve6(const double Hin[36], const double b[6], double x[6]) { orc_eig_svd_solve6(Hin, b, x); }
 
 /* ---- More-Thuente  :593-690 ------------------------------------------------------------------- */
 static int update_interval(double *a_l, double *f_l, double *g_l, double *a_u, double *f_u, double *g_u, double a_t, double f_t, double g_t) {

@@ -544,11 +544,19 @@ static double model_linearize(oracle *o, const double T[16], double *H, double *
 }
 
 static double model_compute_error(oracle *o, const double T[16]) {
+  double cost;
   o->num_compute_error++;
   switch (o->cfg.model) {
-    case ORC_MODEL_P2PLANE: return p2plane_compute_error(o, T);
-    default: return orc_gauss_compute_error(o, T);
+    case ORC_MODEL_P2PLANE: cost = p2plane_compute_error(o, T); break;
+    default: cost = orc_gauss_compute_error(o, T); break;
   }
+  if (o->trace && o->trace_n < o->trace_max) {   /* trial record: cost, then NaN in the H / b slots */
+    double *r = o->trace + (size_t)o->trace_n * 43;
+    r[0] = cost;
+    for (int k = 1; k < 43; k++) r[k] = NAN;
+    o->trace_n++;
+  }
+  return cost;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -599,8 +607,9 @@ static int step_lm(oracle *o, double x0[16], double delta[16]) {
     orc_delta_from_d(d, delta);
     orc_iso_mul(delta, x0, xi);
     double yi = model_compute_error(o, xi);
-    double den = 0.0;
-    for (int k = 0; k < 6; k++) den += d[k] * (o->lm_lambda * d[k] - b[k]);
+    double dp[6];
+    for (int k = 0; k < 6; k++) dp[k] = d[k] * (o->lm_lambda * d[k] - b[k]);
+    const double den = orc_redux_fixed_d(dp, 6);   /* d.dot(lm_lambda_ * d - b)  :146: fixed size 6, Packet2d ([CORE-1], orc_eigen.h) */
     double rho = (y0 - yi) / den;
     if (rho < 0) {
       if (is_converged(o, delta)) return 1;
@@ -771,3 +780,32 @@ long orc_test_voxel_key(void *h, const float p[3], int key[3]) {
   orc_ivox_key(o, p, key);
   return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* batch hooks for the Eigen restatements of orc_eigen.h (tests/test_eigen_restatements.py checks every one of them  */
+/* against float64 numpy on >= 10 000 random cases)                                                                   */
+/* ------------------------------------------------------------------------- */
+void orc_test_eig_ldlt6(long n, const double *A, const double *b, double *x) {
+  for (long i = 0; i < n; i++) orc_eig_ldlt6_solve(A + 36 * i, b + 6 * i, x + 6 * i);
+}
+void orc_test_eig_colpivqr_f(long n, int rows, const float *A, const float *b, float *x) {
+  for (long i = 0; i < n; i++) orc_eig_colpivqr3f(A + (long)rows * 3 * i, rows, b + (long)rows * i, x + 3 * i);
+}
+void orc_test_eig_colpivqr_d(long n, int rows, const double *A, const double *b, double *x) {
+  for (long i = 0; i < n; i++) orc_eig_colpivqr3d(A + (long)rows * 3 * i, rows, b + (long)rows * i, x + 3 * i);
+}
+void orc_test_eig_jacobi_svd(long n, int dim, const double *A, double *U, double *S, double *V) {
+  for (long i = 0; i < n; i++) orc_eig_jacobi_svd(dim, A + (long)dim * dim * i, U + (long)dim * dim * i, S + (long)dim * i, V + (long)dim * dim * i);
+}
+void orc_test_eig_svd_solve6(long n, const double *A, const double *b, double *x) {
+  for (long i = 0; i < n; i++) orc_eig_svd_solve6(A + 36 * i, b + 6 * i, x + 6 * i);
+}
+void orc_test_eig_selfadjoint3(long n, const double *A, double *w, double *V, int *ok) {
+  for (long i = 0; i < n; i++) ok[i] = orc_eig_selfadjoint3(A + 9 * i, w + 3 * i, V + 9 * i);
+}
+void orc_test_eig_direct3f(long n, const float *A, float *w, float *V) {
+  for (long i = 0; i < n; i++) orc_eig_direct3f(A + 9 * i, w + 3 * i, V + 9 * i);
+}
+void orc_test_eig_inv3d(long n, const double *A, double *R) { for (long i = 0; i < n; i++) orc_eig_inv3d(A + 9 * i, R + 9 * i); }
+void orc_test_eig_inv3f(long n, const float *A, float *R) { for (long i = 0; i < n; i++) orc_eig_inv3f(A + 9 * i, R + 9 * i); }
+void orc_test_eig_inv4d(long n, const double *A, double *R) { for (long i = 0; i < n; i++) orc_eig_inv4d(A + 16 * i, R + 16 * i); }

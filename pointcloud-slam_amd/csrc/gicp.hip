@@ -147,40 +147,40 @@ __device__ inline void regularize_cov(int method, const double (&cov)[9], double
     for (int a = 0; a < 9; a++) C[a] = cov[a];
     C[0] += 1e-3; C[4] += 1e-3; C[8] += 1e-3;
     inv3<double>(C, Ci);
-    double nrm = 0.0;
+    // Matrix3d::norm(): fixed-size sum over the column-major coefficients: four packets of two by a tree, then the ninth (CORE-1)
+    double sq[9];
 #pragma unroll
-    for (int a = 0; a < 9; a++) nrm += Ci[a] * Ci[a];
-    nrm = sqrt(nrm);
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int b = 0; b < 3; b++) sq[b * 3 + a] = Ci[a * 3 + b] * Ci[a * 3 + b];
+    }
+    const double nrm = sqrt((((sq[0] + sq[2]) + (sq[4] + sq[6])) + ((sq[1] + sq[3]) + (sq[5] + sq[7]))) + sq[8]);
 #pragma unroll
     for (int a = 0; a < 9; a++) N[a] = Ci[a] / nrm;
     inv3<double>(N, out);
     return;
   }
-  double w[3], V[9], val[3];
-  eig3_sym_jacobi(cov, w, V);   // ascending; the SVD's singular values are these in descending order
-  if (method == PCM_REG_PLANE) { val[0] = 1e-3; val[1] = 1.0; val[2] = 1.0; }
+  // Eigen::JacobiSVD<Matrix3d>(cov, ComputeFullU | ComputeFullV)  :273 (two-sided Jacobi, dev_linalg.h)
+  double U[9], S[3], V[9], val[3];
+  jacobi_svd<3>(cov, U, S, V);
+  if (method == PCM_REG_PLANE) { val[0] = 1.0; val[1] = 1.0; val[2] = 1e-3; }                                  // :280
   else if (method == PCM_REG_MIN_EIG) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) val[k] = w[k] > 1e-3 ? w[k] : 1e-3;
+    for (int k = 0; k < 3; k++) val[k] = S[k] > 1e-3 ? S[k] : 1e-3;                                            // :283
   } else {
 #pragma unroll
-    for (int k = 0; k < 3; k++) { const double v = w[k] / w[2]; val[k] = v > 1e-3 ? v : 1e-3; }
+    for (int k = 0; k < 3; k++) { const double v = S[k] / S[0]; val[k] = v > 1e-3 ? v : 1e-3; }                // :286-287
   }
+  // svd.matrixU() * values.asDiagonal() * svd.matrixV().transpose()  :292
 #pragma unroll
   for (int a = 0; a < 3; a++) {
 #pragma unroll
-    for (int b = 0; b < 3; b++) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; k++) s += V[a * 3 + k] * val[k] * V[b * 3 + k];
-      out[a * 3 + b] = s;
-    }
+    for (int b = 0; b < 3; b++) out[a * 3 + b] = ((U[a * 3 + 0] * val[0]) * V[b * 3 + 0] + (U[a * 3 + 1] * val[1]) * V[b * 3 + 1]) + (U[a * 3 + 2] * val[2]) * V[b * 3 + 2];
   }
 }
 
 // covariance_regularization.cu:14-121 (float): PLANE / MIN_EIG through V diag V^-1 with the general inverse of the
 // eigenvector matrix, FROBENIUS; the other methods are unimplemented there and leave the matrix as it is.
-// (Eigen's float computeDirect is replaced by the cyclic Jacobi in double, cast to float.)
 __device__ inline void regularize_cov_f(int method, float (&c)[9]) {
   if (method == PCM_REG_FROBENIUS) {
     float C[9], Ci[9], N[9];
@@ -198,20 +198,13 @@ __device__ inline void regularize_cov_f(int method, float (&c)[9]) {
     return;
   }
   if (method != PCM_REG_PLANE && method != PCM_REG_MIN_EIG) return;
-  double sym[9], w[3], V[9];
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int b = 0; b < 3; b++) sym[a * 3 + b] = (double)c[(a > b ? a : b) * 3 + (a > b ? b : a)];
-  }
-  eig3_sym_jacobi(sym, w, V);
-  float Vf[9], Vi[9], val[3], VD[9];
-#pragma unroll
-  for (int a = 0; a < 9; a++) Vf[a] = (float)V[a];
+  // SelfAdjointEigenSolver<Matrix3f>::computeDirect  covariance_regularization.cu:57-58,84-85 (closed form, dev_linalg.h)
+  float w[3], Vf[9], Vi[9], val[3], VD[9];
+  selfadjoint3_direct(c, w, Vf);
   if (method == PCM_REG_PLANE) { val[0] = 1e-3f; val[1] = 1.0f; val[2] = 1.0f; }
   else {
 #pragma unroll
-    for (int k = 0; k < 3; k++) val[k] = fmaxf(1e-3f, (float)w[k]);
+    for (int k = 0; k < 3; k++) val[k] = fmaxf(1e-3f, w[k]);
   }
   inv3<float>(Vf, Vi);
 #pragma unroll
@@ -485,15 +478,15 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
         cov[b * 3 + a] = cov[a * 3 + b];
       }
     }
-    double w[3], V[9], R[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    eig3_sym_jacobi(cov, w, V);   // ascending
+    double U[9], S[3], R[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    jacobi_svd<3, true, false>(cov, U, S, nullptr);   // JacobiSVD<Matrix3d>(cov, ComputeFullU)  gicp_omp_impl.hpp:110
     const double val[3] = {1.0, 1.0, 0.001};
 #pragma unroll
-    for (int kk = 0; kk < 3; kk++) {
+    for (int kk = 0; kk < 3; kk++) {        // cov += v * col * col.transpose()  :114-120
 #pragma unroll
       for (int a = 0; a < 3; a++) {
 #pragma unroll
-        for (int b = 0; b < 3; b++) R[a * 3 + b] += (val[kk] * V[a * 3 + (2 - kk)]) * V[b * 3 + (2 - kk)];
+        for (int b = 0; b < 3; b++) R[a * 3 + b] += (val[kk] * U[a * 3 + kk]) * U[b * 3 + kk];
       }
     }
     double* o = out + (size_t)i * 6;
@@ -697,8 +690,24 @@ __global__ void __launch_bounds__(256) k_gicp(const PairDesc* __restrict__ descs
 #pragma unroll
           for (int b = 0; b < 3; b++) S[a * 3 + b] = CB[a * 3 + b] + (RC[a * 3 + 0] * T[b * 4 + 0] + RC[a * 3 + 1] * T[b * 4 + 1] + RC[a * 3 + 2] * T[b * 4 + 2]);
         }
-        inv3<double>(S, M);
-        M[3] = M[1]; M[6] = M[2]; M[7] = M[5];   // stored symmetric (upper triangle)
+        {   // the reference inverts the 4 x 4 matrix with (3,3) = 1: Eigen's pair-of-doubles 4x4 inverse (dev_linalg.h)
+          double S4[16], I4[16];
+#pragma unroll
+          for (int a = 0; a < 16; a++) S4[a] = 0.0;
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+#pragma unroll
+            for (int b = 0; b < 3; b++) S4[a * 4 + b] = S[a * 3 + b];
+          }
+          S4[15] = 1.0;
+          inv4d(S4, I4);
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+#pragma unroll
+            for (int b = 0; b < 3; b++) M[a * 3 + b] = I4[a * 4 + b];
+          }
+        }
+        M[3] = M[1]; M[6] = M[2]; M[7] = M[5];   // stored symmetric (upper triangle; the two triangles differ by rounding only)
         gstore_d(mp + 0, M[0]); gstore_d(mp + 1, M[1]); gstore_d(mp + 2, M[2]);
         gstore_d(mp + 3, M[4]); gstore_d(mp + 4, M[5]); gstore_d(mp + 5, M[8]);
       }

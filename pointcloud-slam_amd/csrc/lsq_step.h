@@ -8,13 +8,16 @@
 // round trip: LINEARIZE round -> (LM only) TRIAL rounds -> next LINEARIZE.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PCM_HD __host__ __device__ inline
+#else
+#define PCM_HD inline   // plain host build: tests/test_capi_and_host.py replays GN / LM traces through this header with g++
+#endif
 
 namespace pcm {
-
-#define PCM_HD __host__ __device__ inline
 
 enum PairMode : int32_t { MODE_LINEARIZE = 0, MODE_TRIAL = 1, MODE_DONE = 2, MODE_WAIT = 3 };   // WAIT: queued behind the batch window
 
@@ -86,40 +89,96 @@ PCM_HD void delta_from_d(const double* d, double* delta) {
   delta[12] = 0; delta[13] = 0; delta[14] = 0; delta[15] = 1;
 }
 
-// LDL^T with diagonal pivoting (what Eigen::LDLT does, lsq_registration_impl.hpp:111,136)
+// balanced tree over n terms, the order of Eigen's unrolled scalar reduction (redux_novec_unroller): f(lo half, hi half)
+template <int N>
+PCM_HD double eig_tree_sum(const double* v) {
+  if constexpr (N == 1) return v[0];
+  else return eig_tree_sum<N / 2>(v) + eig_tree_sum<N - N / 2>(v + N / 2);
+}
+// fixed-size contiguous doubles: Packet2d accumulators combined by the same tree, horizontal add, then the odd tail
+template <int N>
+PCM_HD double eig_fixed_sum(const double* v) {
+  if constexpr (N == 1) {
+    return v[0];
+  } else {
+    constexpr int NP = N / 2;
+    double lo[NP], hi[NP];
+    for (int i = 0; i < NP; i++) { lo[i] = v[2 * i]; hi[i] = v[2 * i + 1]; }
+    double r = eig_tree_sum<NP>(lo) + eig_tree_sum<NP>(hi);
+    if constexpr (N % 2) r = r + v[N - 1];
+    return r;
+  }
+}
+
+// Eigen::LDLT<Matrix<double,6,6>>(A).solve(rhs)  (lsq_registration_impl.hpp:111,136), restated from the Eigen sources in
+// the reference tree (E = /root/reference/src/pointcloud_match/fast_gicp/thirdparty/Eigen/Eigen/src):
+//   compute  E/Cholesky/LDLT.h:497-530 -> ldlt_inplace<Lower>::unblocked :297-390: left-looking, pivot = largest |diagonal|
+//            of the trailing block (first of equal maxima), transposition on the LOWER triangle only (the upper one is never read)
+//   solve    E/Cholesky/LDLT.h:569-611: P b, unit-lower solve, D^-1 with the pivots <= numeric_limits::min dropped, L^T solve, P^T
+// Eigen/Core is not in that tree: the order of additions inside its reductions and the unrolled row-oriented substitution
+// for the fixed-size right-hand side follow upstream Eigen 3.4 on SSE2 (assumptions CORE-1..3).
+template <int I>
+PCM_HD void ldlt6_forward(const double (&m)[6][6], double (&y)[6]) {
+  if constexpr (I < 6) {
+    double prod[I];
+    for (int j = 0; j < I; j++) prod[j] = m[I][j] * y[j];          // row of a column-major matrix: strided -> tree sum
+    y[I] -= eig_tree_sum<I>(prod);
+    ldlt6_forward<I + 1>(m, y);
+  }
+}
+template <int L>
+PCM_HD void ldlt6_backward(const double (&m)[6][6], double (&y)[6]) {
+  if constexpr (L < 6) {
+    constexpr int i = 6 - L - 1;
+    double prod[L];
+    for (int j = 0; j < L; j++) prod[j] = m[i + 1 + j][i] * y[i + 1 + j];   // column of L below the diagonal: contiguous -> packets
+    y[i] -= eig_fixed_sum<L>(prod);
+    ldlt6_backward<L + 1>(m, y);
+  }
+}
 PCM_HD void ldlt6_solve(const double* Ain, const double* rhs, double* x) {
-  double A[36];
-  int perm[6];
-  for (int i = 0; i < 36; i++) A[i] = Ain[i];
-  for (int i = 0; i < 6; i++) perm[i] = i;
+  double m[6][6], temp[6];
+  int tr[6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) m[i][j] = Ain[i * 6 + j];
+  for (int k = 0; k < 6; k++) tr[k] = k;
   for (int k = 0; k < 6; k++) {
-    int p = k;
-    double best = fabs(A[k * 6 + k]);
+    int big = k;
+    double best = fabs(m[k][k]);
     for (int i = k + 1; i < 6; i++) {
-      const double v = fabs(A[i * 6 + i]);
-      if (v > best) { best = v; p = i; }
+      const double v = fabs(m[i][i]);
+      if (v > best) { best = v; big = i; }
     }
-    if (p != k) {
-      for (int j = 0; j < 6; j++) { const double t = A[k * 6 + j]; A[k * 6 + j] = A[p * 6 + j]; A[p * 6 + j] = t; }
-      for (int i = 0; i < 6; i++) { const double t = A[i * 6 + k]; A[i * 6 + k] = A[i * 6 + p]; A[i * 6 + p] = t; }
-      const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+    tr[k] = big;
+    if (k != big) {
+      for (int j = 0; j < k; j++) { const double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
+      for (int i = big + 1; i < 6; i++) { const double t = m[i][k]; m[i][k] = m[i][big]; m[i][big] = t; }
+      { const double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
+      for (int i = k + 1; i < big; i++) { const double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
     }
-    const double dk = A[k * 6 + k];
-    if (dk == 0.0) continue;
-    for (int i = k + 1; i < 6; i++) A[i * 6 + k] /= dk;
-    for (int i = k + 1; i < 6; i++) {
-      for (int j = k + 1; j <= i; j++) {
-        A[i * 6 + j] -= A[i * 6 + k] * dk * A[j * 6 + k];
-        A[j * 6 + i] = A[i * 6 + j];
+    if (k > 0) {   // temp = D(0:k) .* A10^T ; A(k,k) -= A10 . temp ; A21 -= A20 * temp  (strided runtime-size operands: left to right)
+      for (int j = 0; j < k; j++) temp[j] = m[j][j] * m[k][j];
+      double s = m[k][0] * temp[0];
+      for (int j = 1; j < k; j++) s = s + m[k][j] * temp[j];
+      m[k][k] -= s;
+      for (int i = k + 1; i < 6; i++) {
+        double t = m[i][0] * temp[0];
+        for (int j = 1; j < k; j++) t = t + m[i][j] * temp[j];
+        m[i][k] -= t;
       }
     }
+    const double akk = m[k][k];
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) { for (int j = 0; j < 6; j++) tr[j] = j; break; }
+    if (k < 5 && valid) for (int i = k + 1; i < 6; i++) m[i][k] /= akk;
   }
   double y[6];
-  for (int i = 0; i < 6; i++) y[i] = rhs[perm[i]];
-  for (int i = 0; i < 6; i++) for (int j = 0; j < i; j++) y[i] -= A[i * 6 + j] * y[j];
-  for (int i = 0; i < 6; i++) y[i] = (fabs(A[i * 6 + i]) > 2.2250738585072014e-308) ? y[i] / A[i * 6 + i] : 0.0;
-  for (int i = 5; i >= 0; i--) for (int j = i + 1; j < 6; j++) y[i] -= A[j * 6 + i] * y[j];
-  for (int i = 0; i < 6; i++) x[perm[i]] = y[i];
+  for (int i = 0; i < 6; i++) y[i] = rhs[i];
+  for (int k = 0; k < 6; k++) if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  ldlt6_forward<1>(m, y);
+  for (int i = 0; i < 6; i++) y[i] = (fabs(m[i][i]) > 2.2250738585072014e-308) ? y[i] / m[i][i] : 0.0;
+  ldlt6_backward<1>(m, y);
+  for (int k = 5; k >= 0; k--) if (tr[k] != k) { const double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
+  for (int i = 0; i < 6; i++) x[i] = y[i];
 }
 
 // is_converged  (lsq_registration_impl.hpp:81-91)
@@ -193,8 +252,9 @@ PCM_HD void after_linearize(PairState& s, const LsqParams& p, const double* H, c
 // Called after a TRIAL round produced cost yi at xi  (:144-171)
 PCM_HD void after_trial(PairState& s, const LsqParams& p, double yi) {
   s.num_compute_error += 1;
-  double den = 0.0;
-  for (int k = 0; k < 6; k++) den += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
+  double dp[6];
+  for (int k = 0; k < 6; k++) dp[k] = s.d[k] * (s.lambda * s.d[k] - s.b[k]);
+  const double den = eig_fixed_sum<6>(dp);   // d.dot(lm_lambda_ * d - b)  lsq_registration_impl.hpp:146: fixed-size 6, packets of two
   const double rho = (s.y0 - yi) / den;
   if (rho < 0) {
     if (is_converged(p, s.delta)) { finish_outer(s, p, true); return; }

@@ -17,6 +17,7 @@
 // must re-use the correspondences of the last linearize.
 // Compiled with -ffp-contract=off (see kernels.hip).
 #include "pcm_device.h"
+#include "dev_linalg.h"
 #include "pcm_host.h"
 
 namespace pcm {
@@ -61,17 +62,8 @@ __device__ inline void load_gvox(const GaussVoxel* g, float (&mean)[3], float (&
   C[0] = b.x; C[1] = b.y; C[2] = b.z; C[3] = b.y; C[4] = b.w; C[5] = c.x; C[6] = b.z; C[7] = c.x; C[8] = c.y;
 }
 
-// Eigen fixed-size 3x3 inverse (cofactors / determinant), float
-__device__ inline void inv3f(const float (&m)[9], float (&inv)[9]) {
-  const float c00 = m[4] * m[8] - m[5] * m[7];
-  const float c01 = m[5] * m[6] - m[3] * m[8];
-  const float c02 = m[3] * m[7] - m[4] * m[6];
-  const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-  const float id = 1.0f / det;
-  inv[0] = c00 * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-  inv[3] = c01 * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-  inv[6] = c02 * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-}
+// Matrix3f::inverse(): Eigen's fixed-size 3x3 inverse (dev_linalg.h: cofactors of column 0, det along that column)
+__device__ inline void inv3f(const float (&m)[9], float (&inv)[9]) { inv3<float>(m, inv); }
 
 __device__ inline double wave_sum_d(double v) {
 #pragma unroll

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict_
 #pragma unroll
       for (int b = 0; b < 3; b++) sym[a * 3 + b] = cov[(a > b ? a : b) * 3 + (a > b ? b : a)];   // self-adjoint view: lower triangle
     }
-    eig3_sym_jacobi(sym, w, V);
+    selfadjoint3(sym, w, V);   // eigensolver.compute(leaf.cov_)  :327 (tridiagonalisation + implicit QR, dev_linalg.h)
     if (w[0] < 0 || w[1] < 0 || w[2] <= 0) {
       n = -1;                                                                                       // :331-335
     } else {

@@ -5,6 +5,7 @@
 //   Matrix3f::eulerAngles(0,1,2), AngleAxis<float>::toRotationMatrix, Translation * AngleAxis products (float),
 //   JacobiSVD<Matrix6d>::solve (one-sided Jacobi; rank threshold diagSize * epsilon * sigma_max).
 #pragma once
+#include "dev_linalg.h"
 
 #include <cfloat>
 #include <cmath>
@@ -107,41 +108,8 @@ struct Solver {
     for (int a = 0; a < 3; a++) res[a] = -res[a];
   }
 
-  static void svd_solve6(const double (&Hin)[36], const double (&b)[6], double (&x)[6]) {
-    double U[36], V[36];
-    std::memcpy(U, Hin, sizeof(U));
-    for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; sweep++) {
-      bool rotated = false;
-      for (int p = 0; p < 5; p++) for (int q = p + 1; q < 6; q++) {
-        double al = 0, be = 0, ga = 0;
-        for (int k = 0; k < 6; k++) { al += U[k * 6 + p] * U[k * 6 + p]; be += U[k * 6 + q] * U[k * 6 + q]; ga += U[k * 6 + p] * U[k * 6 + q]; }
-        if (ga == 0.0 || std::fabs(ga) <= 1e-15 * std::sqrt(al * be)) continue;
-        rotated = true;
-        const double zeta = (be - al) / (2.0 * ga);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
-        for (int k = 0; k < 6; k++) {
-          const double up = U[k * 6 + p], uq = U[k * 6 + q];
-          U[k * 6 + p] = c * up - sn * uq; U[k * 6 + q] = sn * up + c * uq;
-          const double vp = V[k * 6 + p], vq = V[k * 6 + q];
-          V[k * 6 + p] = c * vp - sn * vq; V[k * 6 + q] = sn * vp + c * vq;
-        }
-      }
-      if (!rotated) break;
-    }
-    double sig[6], smax = 0.0;
-    for (int j = 0; j < 6; j++) { double n2 = 0; for (int k = 0; k < 6; k++) n2 += U[k * 6 + j] * U[k * 6 + j]; sig[j] = std::sqrt(n2); if (sig[j] > smax) smax = sig[j]; }
-    double thr = smax * 6.0 * DBL_EPSILON;
-    if (thr < DBL_MIN) thr = DBL_MIN;
-    for (int i = 0; i < 6; i++) x[i] = 0.0;
-    for (int j = 0; j < 6; j++) {
-      if (!(sig[j] > thr)) continue;
-      double ub = 0;
-      for (int k = 0; k < 6; k++) ub += (U[k * 6 + j] / sig[j]) * b[k];
-      for (int i = 0; i < 6; i++) x[i] += V[i * 6 + j] * (ub / sig[j]);
-    }
-  }
+  // Eigen::JacobiSVD<Matrix6d>(H, ComputeFullU | ComputeFullV).solve(b)  ndt_omp_impl.hpp:112-114 (two-sided Jacobi, dev_linalg.h)
+  static void svd_solve6(const double (&Hin)[36], const double (&b)[6], double (&x)[6]) { pcm::svd_solve6(Hin, b, x); }
 
   static bool update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t, double g_t) {   // :593-625
     if (f_t > f_l) { a_u = a_t; f_u = f_t; g_u = g_t; return false; }

@@ -3,8 +3,8 @@
 // common::esti_plane (/root/reference/src/jueying_lio/include/common_lib.h:186-243):
 // solve A x = -1 with Eigen's ColPivHouseholderQR (float for exactly 5 points,
 // double otherwise), n = x/|x|, d = 1/|x|, reject when any |n.p_j + d| > threshold.
-// Host+device so the arithmetic can be unit-checked on the CPU (tests/test_host_math.py
-// compiles it with g++); the shipped path only ever calls it from the HIP kernel.
+// Host+device so the arithmetic can be unit-checked on the CPU (tests/test_capi_and_host.py compiles it with g++ and
+// compares it bit for bit with the CPU restatement under test); the shipped path only ever calls it from the HIP kernel.
 #pragma once
 
 #include <math.h>
@@ -35,143 +35,195 @@ PCM_HD_FN inline float pcm_divf_rn(float a, float b) {
 }
 
 // ---------------------------------------------------------------------------
-// Eigen::ColPivHouseholderQR<Matrix<T,R,3>>(A).solve(-ones)  (common_lib.h:199-208,
-// 210-226).  A is column-major in registers: A[col][row].  All loops are fully
-// unrolled so every index is a compile-time constant (no scratch memory).
+// Eigen::ColPivHouseholderQR<Matrix<T,R,3>>(A).solve(-ones)  (common_lib.h:199-208, 210-226), restated from the Eigen
+// sources in the reference tree (E = /root/reference/src/pointcloud_match/fast_gicp/thirdparty/Eigen/Eigen/src):
+//   computeInPlace   E/QR/ColPivHouseholderQR.h:482-580     makeHouseholder  E/Householder/Householder.h:66-98
+//   applyHouseholderOnTheLeft  E/Householder/Householder.h:116-137
+//   solve            E/QR/ColPivHouseholderQR.h:585-608, reflectors one by one (E/Householder/HouseholderSequence.h:402-413)
+// Eigen/Core is not in that tree; the order of additions inside its reductions and the form of its triangular solve are
+// restated from upstream Eigen 3.4 as the reference's SSE2 builds run them (assumptions CORE-1 and CORE-2):
+// a contiguous run of n scalars is summed packet-wise -- float: ((v0+v2)+(v1+v3)) + v4.. for n >= 4, double:
+// (v0+v2)+(v1+v3) for n = 4 -- and left to right below one packet; the back substitution is column-oriented.
+// A is column-major in registers: A[col][row].  All loops are fully unrolled so every index is a compile-time constant
+// (no scratch memory).
 // ---------------------------------------------------------------------------
 template <typename T> struct Num;
 template <> struct Num<float> {
+  static constexpr int kPacket = 4;
   static PCM_HD_FN float eps() { return 1.1920929e-07f; }
   static PCM_HD_FN float tmin() { return 1.17549435e-38f; }
   static PCM_HD_FN float sqrt_(float v) { return pcm_sqrtf_rn(v); }
   static PCM_HD_FN float div_(float a, float b) { return pcm_divf_rn(a, b); }
 };
 template <> struct Num<double> {
+  static constexpr int kPacket = 2;
   static PCM_HD_FN double eps() { return 2.220446049250313e-16; }
   static PCM_HD_FN double tmin() { return 2.2250738585072014e-308; }
   static PCM_HD_FN double sqrt_(double v) { return sqrt(v); }
   static PCM_HD_FN double div_(double a, double b) { return a / b; }
 };
 
+// sum of N (<= 2 packets) contiguous scalars in the order Eigen's vectorised reduction adds them
+template <typename T, int N>
+PCM_HD_FN inline T eig_redux(const T (&v)[N < 1 ? 1 : N]) {
+  constexpr int P = Num<T>::kPacket;
+  if constexpr (N <= 0) {
+    return (T)0;
+  } else if constexpr (N < P) {
+    T r = v[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) r = r + v[i];
+    return r;
+  } else {
+    static_assert(N < 3 * P, "eig_redux: at most two packets and a tail");
+    T p[P];
+#pragma unroll
+    for (int l = 0; l < P; l++) p[l] = v[l];
+    if constexpr (N >= 2 * P) {
+#pragma unroll
+      for (int l = 0; l < P; l++) p[l] = p[l] + v[P + l];
+    }
+    T r;
+    if constexpr (P == 4) r = (p[0] + p[2]) + (p[1] + p[3]);
+    else r = p[0] + p[1];
+#pragma unroll
+    for (int i = (N / P) * P; i < N; i++) r = r + v[i];
+    return r;
+  }
+}
+
+// dot of the trailing TL entries of two columns (rows k+1 .. R-1)
+template <typename T, int R, int K0>
+PCM_HD_FN inline T eig_tail_dot(const T (&x)[R], const T (&y)[R]) {
+  constexpr int TL = R - K0 - 1;
+  if constexpr (TL <= 0) {
+    return (T)0;
+  } else {
+    T prod[TL];
+#pragma unroll
+    for (int i = 0; i < TL; i++) prod[i] = x[K0 + 1 + i] * y[K0 + 1 + i];
+    return eig_redux<T, TL>(prod);
+  }
+}
+
+template <typename T, int R, int K0>
+PCM_HD_FN inline void colpiv_qr_step(T (&A)[3][R], T (&nu)[3], T (&nd)[3], int (&perm)[3], T (&hc)[3], int& nonzero, T thr_helper, T downdate_thr) {
+  constexpr int k = K0;
+  int big = k;
+  T bign = nu[k];
+#pragma unroll
+  for (int j = k + 1; j < 3; j++) {
+    if (nu[j] > bign) { bign = nu[j]; big = j; }
+  }
+  if (nonzero == 3 && bign * bign < thr_helper * (T)(R - k)) nonzero = k;
+#pragma unroll
+  for (int j = k + 1; j < 3; j++) {
+    if (big == j) {
+#pragma unroll
+      for (int i = 0; i < R; i++) { const T t = A[k][i]; A[k][i] = A[j][i]; A[j][i] = t; }
+      T t = nu[k]; nu[k] = nu[j]; nu[j] = t;
+      t = nd[k]; nd[k] = nd[j]; nd[j] = t;
+      const int ti = perm[k]; perm[k] = perm[j]; perm[j] = ti;
+    }
+  }
+  // makeHouseholderInPlace on A[k][k..R)
+  const T tail_sq = eig_tail_dot<T, R, k>(A[k], A[k]);
+  const T c0 = A[k][k];
+  T beta, tau;
+  if (tail_sq <= Num<T>::tmin()) {
+    tau = 0;
+    beta = c0;
+#pragma unroll
+    for (int i = k + 1; i < R; i++) A[k][i] = 0;
+  } else {
+    beta = Num<T>::sqrt_(c0 * c0 + tail_sq);
+    if (c0 >= 0) beta = -beta;
+    const T den = c0 - beta;
+#pragma unroll
+    for (int i = k + 1; i < R; i++) A[k][i] = Num<T>::div_(A[k][i], den);
+    tau = Num<T>::div_(beta - c0, beta);
+  }
+  A[k][k] = beta;
+  hc[k] = tau;
+#pragma unroll
+  for (int j = k + 1; j < 3; j++) {
+    if (R - k == 1) {
+      A[j][k] *= ((T)1 - tau);
+    } else if (tau != 0) {
+      T tmp = eig_tail_dot<T, R, k>(A[k], A[j]);
+      tmp += A[j][k];
+      A[j][k] -= tau * tmp;
+#pragma unroll
+      for (int i = k + 1; i < R; i++) A[j][i] -= tmp * (tau * A[k][i]);
+    }
+  }
+#pragma unroll
+  for (int j = k + 1; j < 3; j++) {
+    if (nu[j] != 0) {
+      T temp = Num<T>::div_(fabs(A[j][k]), nu[j]);
+      temp = ((T)1 + temp) * ((T)1 - temp);
+      temp = temp < 0 ? (T)0 : temp;
+      const T r = Num<T>::div_(nu[j], nd[j]);
+      const T temp2 = temp * (r * r);
+      if (temp2 <= downdate_thr) {
+        nd[j] = nu[j] = Num<T>::sqrt_(eig_tail_dot<T, R, k>(A[j], A[j]));
+      } else {
+        nu[j] *= Num<T>::sqrt_(temp);
+      }
+    }
+  }
+}
+
+template <typename T, int R, int K0>
+PCM_HD_FN inline void colpiv_qr_reflect_rhs(const T (&A)[3][R], const T (&hc)[3], int nonzero, T (&c)[R]) {
+  constexpr int k = K0;
+  if (k < nonzero) {
+    const T tau = hc[k];
+    if (R - k == 1) {
+      c[k] *= ((T)1 - tau);
+    } else if (tau != 0) {
+      T tmp = eig_tail_dot<T, R, k>(A[k], c);
+      tmp += c[k];
+      c[k] -= tau * tmp;
+#pragma unroll
+      for (int i = k + 1; i < R; i++) c[i] -= tmp * (tau * A[k][i]);
+    }
+  }
+}
+
 template <typename T, int R>
 PCM_HD_FN inline void colpiv_qr_solve(T (&A)[3][R], T (&x)[3]) {
   T nu[3], nd[3];
   int perm[3] = {0, 1, 2};
-  T hc[3];
+  T hc[3] = {0, 0, 0};
   T c[R];
   T maxnorm = 0;
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    T s = 0;
+    T prod[R];
 #pragma unroll
-    for (int i = 0; i < R; i++) s += A[j][i] * A[j][i];
-    nu[j] = nd[j] = Num<T>::sqrt_(s);
+    for (int i = 0; i < R; i++) prod[i] = A[j][i] * A[j][i];
+    nu[j] = nd[j] = Num<T>::sqrt_(eig_redux<T, R>(prod));
     maxnorm = nu[j] > maxnorm ? nu[j] : maxnorm;
   }
   const T thr_helper = Num<T>::div_((maxnorm * Num<T>::eps()) * (maxnorm * Num<T>::eps()), (T)R);
   const T downdate_thr = Num<T>::sqrt_(Num<T>::eps());
   int nonzero = 3;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    int big = k;
-    T bign = nu[k];
-#pragma unroll
-    for (int j = k + 1; j < 3; j++) {
-      if (nu[j] > bign) { bign = nu[j]; big = j; }
-    }
-    if (nonzero == 3 && bign * bign < thr_helper * (T)(R - k)) nonzero = k;
-#pragma unroll
-    for (int j = k + 1; j < 3; j++) {
-      if (big == j) {
-#pragma unroll
-        for (int i = 0; i < R; i++) { const T t = A[k][i]; A[k][i] = A[j][i]; A[j][i] = t; }
-        T t = nu[k]; nu[k] = nu[j]; nu[j] = t;
-        t = nd[k]; nd[k] = nd[j]; nd[j] = t;
-        const int ti = perm[k]; perm[k] = perm[j]; perm[j] = ti;
-      }
-    }
-    // makeHouseholderInPlace on A[k][k..R)
-    T tail_sq = 0;
-#pragma unroll
-    for (int i = k + 1; i < R; i++) tail_sq += A[k][i] * A[k][i];
-    const T c0 = A[k][k];
-    T beta, tau;
-    if (tail_sq <= Num<T>::tmin()) {
-      tau = 0;
-      beta = c0;
-#pragma unroll
-      for (int i = k + 1; i < R; i++) A[k][i] = 0;
-    } else {
-      beta = Num<T>::sqrt_(c0 * c0 + tail_sq);
-      if (c0 >= 0) beta = -beta;
-      const T inv = c0 - beta;
-#pragma unroll
-      for (int i = k + 1; i < R; i++) A[k][i] = Num<T>::div_(A[k][i], inv);
-      tau = Num<T>::div_(beta - c0, beta);
-    }
-    A[k][k] = beta;
-    hc[k] = tau;
-#pragma unroll
-    for (int j = k + 1; j < 3; j++) {
-      if (R - k == 1) {
-        A[j][k] *= ((T)1 - tau);
-      } else if (tau != 0) {
-        T tmp = 0;
-#pragma unroll
-        for (int i = k + 1; i < R; i++) tmp += A[k][i] * A[j][i];
-        tmp += A[j][k];
-        A[j][k] -= tau * tmp;
-#pragma unroll
-        for (int i = k + 1; i < R; i++) A[j][i] -= tau * A[k][i] * tmp;
-      }
-    }
-#pragma unroll
-    for (int j = k + 1; j < 3; j++) {
-      if (nu[j] != 0) {
-        T temp = Num<T>::div_(fabs(A[j][k]), nu[j]);
-        temp = ((T)1 + temp) * ((T)1 - temp);
-        temp = temp < 0 ? (T)0 : temp;
-        const T r = Num<T>::div_(nu[j], nd[j]);
-        const T temp2 = temp * r * r;
-        if (temp2 <= downdate_thr) {
-          T s = 0;
-#pragma unroll
-          for (int i = k + 1; i < R; i++) s += A[j][i] * A[j][i];
-          nd[j] = nu[j] = Num<T>::sqrt_(s);
-        } else {
-          nu[j] *= Num<T>::sqrt_(temp);
-        }
-      }
-    }
-  }
+  colpiv_qr_step<T, R, 0>(A, nu, nd, perm, hc, nonzero, thr_helper, downdate_thr);
+  colpiv_qr_step<T, R, 1>(A, nu, nd, perm, hc, nonzero, thr_helper, downdate_thr);
+  colpiv_qr_step<T, R, 2>(A, nu, nd, perm, hc, nonzero, thr_helper, downdate_thr);
 #pragma unroll
   for (int i = 0; i < R; i++) c[i] = (T)-1;
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    if (k < nonzero) {
-      const T tau = hc[k];
-      if (R - k == 1) {
-        c[k] *= ((T)1 - tau);
-      } else if (tau != 0) {
-        T tmp = 0;
-#pragma unroll
-        for (int i = k + 1; i < R; i++) tmp += A[k][i] * c[i];
-        tmp += c[k];
-        c[k] -= tau * tmp;
-#pragma unroll
-        for (int i = k + 1; i < R; i++) c[i] -= tau * A[k][i] * tmp;
-      }
-    }
-  }
+  colpiv_qr_reflect_rhs<T, R, 0>(A, hc, nonzero, c);
+  colpiv_qr_reflect_rhs<T, R, 1>(A, hc, nonzero, c);
+  colpiv_qr_reflect_rhs<T, R, 2>(A, hc, nonzero, c);
+  // upper-triangular solve on the leading nonzero x nonzero block, column-oriented (runtime-size solve of Eigen)
 #pragma unroll
   for (int i = 2; i >= 0; i--) {
-    if (i < nonzero) {
-      T s = c[i];
+    if (i < nonzero && c[i] != 0) {
+      c[i] = Num<T>::div_(c[i], A[i][i]);
 #pragma unroll
-      for (int j = i + 1; j < 3; j++) {
-        if (j < nonzero) s -= A[j][i] * c[j];
-      }
-      c[i] = Num<T>::div_(s, A[i][i]);
+      for (int r = 0; r < i; r++) c[r] -= c[i] * A[i][r];
     }
   }
   x[0] = x[1] = x[2] = 0;

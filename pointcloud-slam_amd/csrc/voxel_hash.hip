@@ -203,21 +203,24 @@ __global__ void k_gauss_voxels(const float4* __restrict__ pts, const uint32_t* _
 #pragma unroll
     for (int b = 0; b < 3; b++) cov[a * 3 + b] = (sxx[a * 3 + b] - mean[a] * sx[b]) / nn;
   }
-  cov[1] = cov[3]; cov[2] = cov[6]; cov[5] = cov[7];   // self-adjoint: lower triangle
-  double w[3], V[9];
-  eig3_sym_jacobi(cov, w, V);
+  // covariance_regularization_mineig (covariance_regularization.cu:83-97) on the float voxel covariance: computeDirect (closed
+  // form, reads the lower triangle; dev_linalg.h), eigenvalues clamped at 1e-3, V diag V^-1 with the general 3x3 inverse
+  float cf[9], w[3], Vf[9], Vi[9], VD[9], c[9];
 #pragma unroll
-  for (int k = 0; k < 3; k++) w[k] = w[k] > 1e-3 ? w[k] : 1e-3;
-  float c[9];
+  for (int a = 0; a < 9; a++) cf[a] = (float)cov[a];
+  selfadjoint3_direct(cf, w, Vf);
+#pragma unroll
+  for (int k = 0; k < 3; k++) w[k] = fmaxf(1e-3f, w[k]);
+  inv3<float>(Vf, Vi);
 #pragma unroll
   for (int a = 0; a < 3; a++) {
 #pragma unroll
-    for (int b = 0; b < 3; b++) {
-      double s = 0.0;
+    for (int b = 0; b < 3; b++) VD[a * 3 + b] = Vf[a * 3 + b] * w[b];
+  }
 #pragma unroll
-      for (int k = 0; k < 3; k++) s += V[a * 3 + k] * w[k] * V[b * 3 + k];
-      c[a * 3 + b] = (float)s;
-    }
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) c[a * 3 + b] = (VD[a * 3 + 0] * Vi[0 * 3 + b] + VD[a * 3 + 1] * Vi[1 * 3 + b]) + VD[a * 3 + 2] * Vi[2 * 3 + b];
   }
   GaussVoxel g;
   g.mx = (float)mean[0]; g.my = (float)mean[1]; g.mz = (float)mean[2];

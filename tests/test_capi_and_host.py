@@ -123,35 +123,61 @@ def test_plane_fit_host_math_equals_oracle_bitwise():
 
 
 def test_lsq_step_host_matches_oracle(synth):
-    """csrc/lsq_step.h (the GN/LM state machine the device runs), compiled for the host,
-    replays an oracle trace: same poses, same LM bookkeeping."""
+    """csrc/lsq_step.h (the GN / LM state machine the device runs: left-looking pivoted LDL^T, so3_exp, convergence test,
+    LM rho / lambda / nu bookkeeping) is compiled for the HOST with g++ and fed the oracle's trace of an align() -- every
+    linearize (cost, H, b) and every trial cost in order: the replay must end in the oracle's pose bit for bit, with the same
+    iteration, linearize and compute_error counts and the same convergence flag, for GN and for LM."""
     from oracle import Oracle, build
     from oracle.loader import result_T
     build()
+    src = r'''
+    #include "lsq_step.h"
+    #include <cstdio>
+    #include <cstdlib>
+    using namespace pcm;
+    int main(int argc, char** argv) {
+      // stdin: optimizer max_iterations lm_max_iterations rot_eps trans_eps lm_init_lambda ; 16 guess floats ; n ; n x 43 records
+      LsqParams lp; double tmp;
+      if (scanf("%d %d %d %lf %lf %lf", &lp.optimizer, &lp.max_iterations, &lp.lm_max_iterations, &lp.rotation_eps, &lp.translation_eps, &lp.lm_init_lambda_factor) != 6) return 2;
+      float guess[16];
+      for (int i = 0; i < 16; i++) { if (scanf("%lf", &tmp) != 1) return 2; guess[i] = (float)tmp; }
+      int n; if (scanf("%d", &n) != 1) return 2;
+      PairState s; init_state(s, guess);
+      int used = 0;
+      for (int r = 0; r < n && s.mode != MODE_DONE; r++) {
+        double rec[43];
+        for (int k = 0; k < 43; k++) { char tok[64]; if (scanf("%63s", tok) != 1) return 2; rec[k] = strtod(tok, nullptr); }
+        const bool trial = rec[1] != rec[1];
+        if (trial != (s.mode == MODE_TRIAL)) { printf("ORDER %d\n", r); return 1; }
+        if (trial) after_trial(s, lp, rec[0]);
+        else after_linearize(s, lp, rec + 1, rec + 37, rec[0], 0);
+        used++;
+      }
+      printf("%d %d %d %d %d %d\n", used, s.mode == MODE_DONE, s.iter, s.converged, s.num_linearize, s.num_compute_error);
+      for (int i = 0; i < 16; i++) printf("%a\n", s.x0[i]);
+      printf("%a %a\n", s.lambda, s.nu);
+      return 0;
+    }'''
+    exe = "/tmp/pcm_lsq_step_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-x", "c++", "-", "-I", os.path.join(ROOT, "pointcloud-slam_amd", "csrc"), "-o", exe],
+                   input=src.encode(), check=True)
     p = synth.make_pair(5, 3000, 40000)
     for opt, oid in (("GN", 0), ("LM", 1)):
-        o = Oracle("P2PLANE", opt, voxel_resolution=0.5, num_neighbors=27)
-        o.set_input_target(p.submap); o.set_input_source(p.scan)
-        o.enable_trace(128)
-        r = o.align(p.guess)
-        tr = o.trace()
-        if opt == "GN":
-            # replay: x <- delta(H,b) * x
-            x = p.guess.astype(np.float64)
-            src = r'''
-            #define __host__
-            #define __device__
-            #include <cstdio>
-            #include <cmath>
-            #include <cstdint>
-            namespace hipstub {}
-            '''
-            from scipy.spatial.transform import Rotation
-            for row in tr:
-                H = row[1:37].reshape(6, 6); b = row[37:43]
-                d = np.linalg.solve(H, -b)
-                D = np.eye(4); D[:3, :3] = Rotation.from_rotvec(d[:3]).as_matrix(); D[:3, 3] = d[3:]
-                x = D @ x
-            assert np.allclose(x, result_T(r), atol=1e-9)
-        else:
-            assert r.num_compute_error >= r.num_linearize - 1 and r.converged
+        for factor in ((1e-9,) if opt == "GN" else (1e-9, 1e-2, 10.0)):   # large initial lambdas force rejected LM trials (rho < 0 branches)
+            o = Oracle("P2PLANE", opt, voxel_resolution=0.5, num_neighbors=27, lm_init_lambda_factor=factor)
+            o.set_input_target(p.submap); o.set_input_source(p.scan)
+            o.enable_trace(512)
+            r = o.align(p.guess)
+            tr = o.trace()
+            assert len(tr) == r.num_linearize + r.num_compute_error
+            text = "%d %d %d %r %r %r\n" % (oid, 64, 10, 2e-3, 5e-4, factor)
+            text += " ".join(repr(float(v)) for v in np.asarray(p.guess, np.float32).reshape(-1)) + "\n%d\n" % len(tr)
+            text += "\n".join(" ".join(float(v).hex() if v == v else "nan" for v in row) for row in tr) + "\n"
+            out = subprocess.run([exe], input=text.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split()
+            used, done, it, conv, nlin, nce = (int(v) for v in out[:6])
+            x = np.array([float.fromhex(v) for v in out[6:22]]).reshape(4, 4)
+            assert used == len(tr) and done == 1
+            assert it == r.iterations and conv == int(r.converged) and nlin == r.num_linearize and nce == r.num_compute_error
+            assert np.array_equal(x, result_T(r)), (opt, factor, np.abs(x - result_T(r)).max())
+        if opt == "LM":
+            assert r.num_compute_error >= r.num_linearize
