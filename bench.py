@@ -39,10 +39,17 @@ def _gen_pair(args):
     return p.scan, p.submap, p.guess, p.T_gt
 
 
+def _profiler_preloaded():
+    """Under rocprofv3 the preloaded tool library initialises the GPU runtime before this script starts: forking then is a fork
+    of a GPU-initialised process (and the tool's signal handler fires in the pool workers at teardown)."""
+    env = os.environ
+    return "rocprof" in env.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCP_TOOL", "ROCPROFILER_", "ROCPROF_")) for k in env)
+
+
 def generate_pairs(ids, n_scan, n_map, workers):
-    """Seeded synthetic pairs, generated on host cores BEFORE anything touches the GPU."""
+    """Seeded synthetic pairs, generated on host cores BEFORE anything touches the GPU (in-process, no pool, when a profiler is preloaded)."""
     jobs = [(i, n_scan, n_map) for i in ids]
-    if workers <= 1 or len(jobs) == 1:
+    if workers <= 1 or len(jobs) == 1 or _profiler_preloaded():
         return [_gen_pair(j) for j in jobs]
     with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
         return pool.map(_gen_pair, jobs)
@@ -54,7 +61,7 @@ def cpu_baseline(pairs, cfg, budget_s):
     from oracle import Oracle
     threads = min(len(os.sched_getaffinity(0)), 16)   # the GPU box's CPU share for one GPU
     t_all = time.perf_counter()
-    n_done, t_align, iters = 0, 0.0, []
+    n_done, t_align, iters, results = 0, 0.0, [], []
     for scan, submap, guess, _ in pairs:
         o = Oracle("P2PLANE", cfg["optimizer"], voxel_resolution=cfg["voxel_resolution"], num_neighbors=cfg["num_neighbors"],
                    max_iterations=cfg["max_iterations"], num_threads=threads)
@@ -65,11 +72,29 @@ def cpu_baseline(pairs, cfg, budget_s):
         r = o.align(guess)
         t_align += time.perf_counter() - t0
         iters.append(r.num_linearize)
+        results.append(r)
         n_done += 1
         if time.perf_counter() - t_all > budget_s:
             break
     return {"value": n_done / t_align, "unit": "registrations/s", "cores": threads, "kind": "port",
-            "sample": "%d of the rank-0 pairs, oracle/ OpenMP restatement, target map prebuilt, mean %.1f linearize passes" % (n_done, float(np.mean(iters)))}
+            "sample": "%d of the rank-0 pairs, oracle/ OpenMP restatement, target map prebuilt, mean %.1f linearize passes" % (n_done, float(np.mean(iters)))}, results
+
+
+def full_size_parity(gpu_results, oracle_results):
+    """Untimed check where the number is produced: the GPU poses of the timed workload against the oracle's on the same
+    full-size pairs (the ones the cpu_baseline leg aligned).  north_star tolerance: 1e-4 m / 1e-4 rad."""
+    from oracle.loader import result_T
+    max_dt = max_dr = 0.0
+    counts_equal = True
+    for rg, ro in zip(gpu_results, oracle_results):
+        D = np.linalg.inv(result_T(ro)) @ rg.T64
+        max_dt = max(max_dt, float(np.linalg.norm(D[:3, 3])))
+        max_dr = max(max_dr, float(np.linalg.norm(D[:3, :3] - np.eye(3))))
+        counts_equal &= (rg.iterations == ro.iterations and rg.num_linearize == ro.num_linearize and rg.num_inliers == ro.num_inliers
+                         and bool(rg.converged) == bool(ro.converged))
+    n = min(len(gpu_results), len(oracle_results))
+    return {"parity_pairs": n, "parity_max_dt_m": max_dt, "parity_max_dr_rad": max_dr, "parity_counts_equal": bool(counts_equal),
+            "parity_ok": bool(n > 0 and max_dt < 1e-4 and max_dr < 1e-4)}
 
 
 def main():
@@ -152,15 +177,18 @@ def main():
     from pointcloud_slam_amd import sharding
     groups = sharding.split_sub_batches(n_local, args.pipeline)
     S = len(groups)
-    pgs = [dist.new_group(list(range(world))) for _ in range(S)] if world > 1 else [None] * S   # one RCCL communicator per pipeline slot
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    # ONE communicator (the default group) and ONE thread that issues every collective, in the order (step, slot) -- the same on
+    # every rank by construction.  (Round 1 gave each pipeline slot its own communicator and let the slot threads issue their
+    # gathers as they finished: rank A could enqueue slot 0 then 1 while rank B enqueued 1 then 0, the documented way to hang
+    # concurrent RCCL communicators.)  The slots keep overlapping their COMPUTE; a slot only waits for the gather of its previous
+    # step before it overwrites that step's result block.
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     bar_kw = {"device_ids": [dev_index]} if (world > 1 and args.backend == "nccl") else {}
-    if world > 1:   # create every communicator here, one after the other, before the slot threads use them concurrently
-        for pg in [None] + pgs:
-            dist.all_reduce(torch.zeros(1, device=dev), group=pg)
+    if world > 1:   # create the communicator before the timed region
+        dist.all_reduce(torch.zeros(1, device=dev))
         torch.cuda.synchronize()
 
-    def sub_step(j):
+    def sub_step(j, before_results=None):
         """One pass of the hot path over sub-batch j."""
         idx = groups[j]
         lo, hi = idx[0], idx[-1] + 1
@@ -168,39 +196,22 @@ def main():
         # again, so the on-device Morton re-ordering is inside the timed step
         for i in idx:
             regs[i].set_input_source(d_inputs[i][0])
-        res = pcm.align_batch([regs[i] for i in idx], guesses[lo:hi], device_out=d_results.data_ptr() + lo * rec)
-        if world > 1:   # RCCL gather of the solved poses over xGMI (one small collective per sub-batch)
-            with torch.cuda.stream(streams[j]):
-                got = sharding.gather_records(d_results[lo * rec:hi * rec], world, group=pgs[j])
-                d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got)
-            streams[j].synchronize()
-        return res
+        if before_results is not None:
+            before_results()     # the gather of this slot's previous result block has been issued and has finished
+        return pcm.align_batch([regs[i] for i in idx], guesses[lo:hi], device_out=d_results.data_ptr() + lo * rec)
+
+    def gather_slot(j):
+        """RCCL all-gather of slot j's solved poses over xGMI (one small collective), complete on return."""
+        lo, hi = groups[j][0], groups[j][-1] + 1
+        with torch.cuda.stream(comm_stream):
+            got = sharding.gather_records(d_results[lo * rec:hi * rec], world)
+            d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got)
+        comm_stream.synchronize()
 
     def run_steps(k, stagger_s=0.0):
-        """k passes over every sub-batch; sub-batch j starts j*stagger_s late so the tails interleave."""
-        last = [None] * S
-        errs = []
-
-        def worker(j):
-            try:
-                torch.cuda.set_device(dev_index)
-                if stagger_s > 0 and j > 0:
-                    time.sleep(j * stagger_s)
-                for _ in range(k):
-                    last[j] = sub_step(j)
-            except Exception as e:   # surfaced in the main thread
-                errs.append(e)
-
-        if S == 1:
-            worker(0)
-        else:
-            ths = [threading.Thread(target=worker, args=(j,)) for j in range(S)]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
-        if errs:
-            raise errs[0]
+        """k passes over every sub-batch (sharding.run_pipelined_steps: slot threads for the compute, one thread for the collectives)."""
+        last = sharding.run_pipelined_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s,
+                                            on_thread_start=lambda: torch.cuda.set_device(dev_index))
         return [r for grp in last for r in grp]
 
     def fence():
@@ -292,7 +303,7 @@ def main():
             "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence)"
                                    % (args.scan_points, args.map_points, args.optimizer),
                        "pairs_per_gpu": n_local, "batches_in_flight": S, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
-                       "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
+                       "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -303,7 +314,10 @@ def main():
                          "residual_kernel_avg_ms": st["residual_ms"] / launches},
         }
         # the CPU leg is timed on rank 0 of the single-GPU run only (the other ranks would idle behind it)
-        out["cpu_baseline"] = cpu_baseline(pairs, cfg, args.cpu_seconds) if (args.cpu_seconds > 0 and world == 1) else None
+        out["cpu_baseline"] = None
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"], oracle_results = cpu_baseline(pairs, cfg, args.cpu_seconds)
+            out["config"].update(full_size_parity(res, oracle_results))   # untimed: the timed GPU poses against the oracle's, full size
     if world > 1:
         dist.barrier(**bar_kw)
         dist.destroy_process_group()

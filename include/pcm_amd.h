@@ -105,11 +105,8 @@ typedef struct pcm_config {
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
-#define PCM_FLAG_FUSED_STEP 2       /* accepted and ignored: since round 2 the GN step of the point-to-plane model is taken by the last workgroup
-                                     * of the search launch by default (write-through hand-off of the partial rows) */
-#define PCM_FLAG_PIPE_KERNEL 8      /* experiment: software-pipelined search kernel, several tiles per workgroup; same results bit for bit, measured slower */
-#define PCM_FLAG_PIPE_DEEP 16       /* test knob: every workgroup of the pipelined kernel walks >= 4 tiles even on an idle device */
-#define PCM_FLAG_SEPARATE_STEP 4    /* take the GN step in a second launch (k_finish_round) instead; same sums in the same order */
+#define PCM_FLAG_FUSED_STEP 2       /* GN: take the step in the search kernel's last workgroup (write-through hand-off of the partial rows) instead of
+                                     * a second launch; same sums in the same order; measured slower at every round size, off by default */
 
 /* out-parameters of align(): getFinalTransformation / hasConverged /
  * getFinalHessian / nr_iterations_  (lsq_registration_impl.hpp:40-79) */

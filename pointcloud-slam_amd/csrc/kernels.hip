@@ -32,7 +32,6 @@
 // Compiled with -ffp-contract=off: the float geometry that feeds discrete
 // decisions (voxel key, kNN order, plane test) must round like the reference's
 // plain x86 build; the double accumulations use explicit fma().
-#include <cstdlib>
 #include "pcm_device.h"
 #include "pcm_host.h"
 #include "plane_fit.h"
@@ -268,6 +267,8 @@ __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restric
                                                        int npairs) {
   const int pair = PCM_PAIR_OF(kp, blockIdx.x);
   const int mode = states[pair].mode;
+  // batch window: a pair that was handed a slot (PENDING) starts with the NEXT round; only its own workgroup changes its mode here
+  if (mode == MODE_PENDING && !trial_round && threadIdx.x == 0) states[pair].mode = MODE_LINEARIZE;
   if (mode == (trial_round ? MODE_TRIAL : MODE_LINEARIZE)) {
     __shared__ double s_grp[32 * kPartialStride];
     __shared__ double s_tot[kPartialStride];
@@ -304,10 +305,12 @@ __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restric
         } else {
           after_trial(st, lp, s_tot[27]);
         }
-        // batch window: a pair that just finished hands its slot to the next queued pair (first active in the next round)
+        // batch window: a pair that just finished hands its slot to the next queued pair.  The queued pair's own workgroup of THIS
+        // launch may already have read its mode (WAIT), so it is only marked PENDING here and promoted by its own workgroup in a
+        // later step launch -- activating it in place raced with that read (stale partial rows summed; round-1 advisor finding)
         if (st.mode == MODE_DONE && queue) {
           const unsigned int next = atomicAdd(queue, 1u);
-          if (next < (unsigned int)npairs) states[next].mode = MODE_LINEARIZE;
+          if (next < (unsigned int)npairs) states[next].mode = MODE_PENDING;
         }
       } else {
         for (int k = 0; k < kNumSums; k++) sums_out[pair * kPartialStride + k] = s_tot[k];
@@ -808,573 +811,6 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
       if (wave == 0) { atomicAdd(&stats[2], use_lds ? 1ull : 0ull); atomicAdd(&stats[3], 1ull); }
     }
   }
-}
-
-// ---------------------------------------------------------------------------
-// k_linearize_pipe: the production form of k_linearize (point-to-plane model, GN and LM rounds).
-//
-// Same arithmetic, same per-tile sums and the same partial-row layout as k_linearize (its results are bit-identical),
-// but a workgroup walks SEVERAL tiles of its pair -- t = blockIdx.x, blockIdx.x + gridDim.x, ... -- and overlaps the
-// dependent memory round trips of tile t+1 with the arithmetic of tile t.  k_linearize spends ~49 % of its wave-cycles
-// parked in s_waitcnt / s_barrier (SQ_WAIT_ANY, profiles/r02_pmc_k_linearize.json): every tile pays the chain
-// scan point -> tile box -> brick probe -> map points before its first compare, and 4 workgroups per CU are all the
-// LDS allows, so nothing else hides it.  Here, per loop iteration (tile t):
-//   S1  the map points of t (already in registers) go to LDS + voxel heads into the cell grid; the prefetched scan
-//       point of t+1 is transformed and reduced to the wave's voxel bounds                                 | barrier
-//   S2  thread 0: tile box of t+1; wave 0: its brick probes are ISSUED (results stay in flight)
-//   S3  27-cell / 5-NN search + plane fit of t out of LDS (the probes land meanwhile)                       | barrier x2
-//   S4  wave 0: probe results -> brick list of t+1; everybody: clear the cell grid, residual row of t      | barrier
-//   S5  staging loads of t+1 and the scan point of t+2 are ISSUED into registers; 29 sums of t, part 1     | barrier
-//   S6  wave 0: 29 sums of t, part 2 -> the tile's partial row
-// GN (FUSED): the partial row is stored write-through, and the arrival ticket of tile t is taken one iteration later
-// (after the wave has drained its memory queue anyway), its returned value checked another phase later: the hand-off to
-// the workgroup that completes the pair's round costs no wait except behind a workgroup's last tile.
-// grid = (gx, pairs launched), block = 256
-// ---------------------------------------------------------------------------
-struct TileCoords {
-  float q[3];
-  int cx, cy, cz;
-  bool search;
-};
-
-__device__ inline TileCoords tile_coords(const PoseF& P, const float4& p, bool live, float inv_res) {
-  TileCoords c;
-  c.q[0] = c.q[1] = c.q[2] = 0.f;
-  c.cx = c.cy = c.cz = 0;
-  c.search = false;
-  if (live) {
-    transform(P, p, c.q);
-    const float fx = roundf(c.q[0] * inv_res), fy = roundf(c.q[1] * inv_res), fz = roundf(c.q[2] * inv_res);  // Pos2Grid  ivox3d.h:283-286
-    const float lim = (float)(kCoordBias - 32);
-    c.search = fabsf(fx) < lim && fabsf(fy) < lim && fabsf(fz) < lim;  // also false for NaN
-    if (c.search) { c.cx = (int)fx; c.cy = (int)fy; c.cz = (int)fz; }
-  }
-  return c;
-}
-
-// wave shuffles with an explicit lane index: inside the tile loop the caller passes a per-iteration opaque lane, so the
-// permute addresses are recomputed (two VALU ops) instead of being hoisted out of the loop and held in registers
-__device__ inline int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
-
-// voxel bounds of the wave's searchable lanes -> s_red[wave][0..5] (min xyz, max xyz)
-__device__ inline void wave_bounds(const TileCoords& c, int (*s_red)[6], int lane, int wave) {
-  const int big = 0x3fffffff;
-  int mn[3] = {c.search ? c.cx : big, c.search ? c.cy : big, c.search ? c.cz : big};
-  int mx[3] = {c.search ? c.cx : -big, c.search ? c.cy : -big, c.search ? c.cz : -big};
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const int src = lane ^ off;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      mn[a] = min(mn[a], bperm_i(src, mn[a]));
-      mx[a] = max(mx[a], bperm_i(src, mx[a]));
-    }
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) { s_red[wave][a] = mn[a]; s_red[wave][3 + a] = mx[a]; }
-  }
-}
-
-// thread 0: tile box (+1 halo), its cell count and the bricks under it -> s_box (origin xyz, dims xyz, ncell, fits)
-// and s_bbox (first brick xyz, brick dims xyz, nbricks); same rules as k_linearize
-__device__ inline void tile_box(const int (*s_red)[6], bool allow_lds, int* s_box, int* s_bbox) {
-  int ncell = 1;
-  bool ok = allow_lds;
-  for (int a = 0; a < 3; a++) {
-    const int mn = min(min(s_red[0][a], s_red[1][a]), min(s_red[2][a], s_red[3][a]));
-    const int mx = max(max(s_red[0][3 + a], s_red[1][3 + a]), max(s_red[2][3 + a], s_red[3][3 + a]));
-    if (mx < mn) { ok = false; s_box[a] = 0; s_box[3 + a] = 0; continue; }  // no searchable lane in this tile
-    const long long dim = (long long)mx - mn + 3;  // +-1 halo for the 27-cell neighbourhood
-    s_box[a] = mn - 1;
-    s_box[3 + a] = (int)(dim < 4096 ? dim : 4096);
-    if (dim > kCapCells) ok = false;
-    ncell = ok ? ncell * (int)dim : ncell;
-    if (ncell > kCapCells) ok = false;
-  }
-  s_bbox[6] = 0;
-  if (ok) {  // bricks under the box
-    int nb = 1;
-    for (int a = 0; a < 3; a++) {
-      const int blo = s_box[a] >> kBrickShift, bhi = (s_box[a] + s_box[3 + a] - 1) >> kBrickShift;
-      s_bbox[a] = blo;
-      s_bbox[3 + a] = bhi - blo + 1;
-      nb *= bhi - blo + 1;
-    }
-    s_bbox[6] = nb;
-    if (nb > kCapBricks) ok = false;
-  }
-  s_box[6] = ncell;
-  s_box[7] = ok ? 1 : 0;
-}
-
-// one brick probe of lane `lane` of wave 0, issued now and resolved later (probe_resolve): only the slot index and the
-// two loaded halves stay in registers across the search
-struct ProbeState {
-  uint32_t h;
-  uint2 k0;   // slot bytes 0..7: the key
-  uint2 k1;   // slot bytes 16..23: first map point, number of map points
-};
-
-__device__ inline void probe_brick_of_lane(const int* s_bbox, int lane, int& bx, int& by, int& bz) {
-  const int nby = s_bbox[4], nbz = s_bbox[5];
-  const int z = lane % nbz, xy = lane / nbz, y = xy % nby, x = xy / nby;
-  bx = s_bbox[0] + x; by = s_bbox[1] + y; bz = s_bbox[2] + z;
-}
-
-__device__ inline ProbeState probe_issue(const BrickSlot* bricks, uint32_t mask, const int* s_box, const int* s_bbox, int lane) {
-  ProbeState ps;
-  ps.h = 0; ps.k0 = make_uint2(0, 0); ps.k1 = make_uint2(0, 0);
-  if (s_box[7] != 0 && lane < s_bbox[6]) {
-    int bx, by, bz;
-    probe_brick_of_lane(s_bbox, lane, bx, by, bz);
-    ps.h = hash_coord(bx, by, bz) & mask;
-    ps.k0 = gload2u(&bricks[ps.h]);
-    ps.k1 = gload2u(reinterpret_cast<const char*>(&bricks[ps.h]) + 16);
-  }
-  return ps;
-}
-
-// wave 0: finish the probes, exclusive scan of the bricks' point counts -> s_borg / s_bps / s_boff, total in
-// s_boff[kCapBricks]; s_box[7] is cleared when the bricks' points do not fit the staging buffer
-__device__ inline void probe_resolve(const BrickSlot* bricks, uint32_t mask, ProbeState ps, int lane, int* s_box, const int* s_bbox, int4* s_borg, uint32_t* s_bps, uint32_t* s_boff) {
-  uint32_t npts = 0, pstart = 0;
-  const bool active = s_box[7] != 0 && lane < s_bbox[6];
-  if (active) {
-    int bx, by, bz;
-    probe_brick_of_lane(s_bbox, lane, bx, by, bz);
-    const uint64_t key = pack_brick(bx, by, bz);
-    for (uint32_t tries = 0; tries <= mask; tries++) {   // bounded: a full sweep of the table ends the probe
-      const uint64_t sk = ((uint64_t)ps.k0.y << 32) | ps.k0.x;
-      if (sk == key) { pstart = ps.k1.x; npts = ps.k1.y; break; }
-      if (sk == kEmptyKey) break;
-      ps.h = (ps.h + 1) & mask;
-      ps.k0 = gload2u(&bricks[ps.h]);
-      ps.k1 = gload2u(reinterpret_cast<const char*>(&bricks[ps.h]) + 16);
-    }
-    s_borg[lane] = make_int4((bx << kBrickShift) - s_box[0], (by << kBrickShift) - s_box[1], (bz << kBrickShift) - s_box[2], 0);
-  }
-  uint32_t incl = npts;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t v = (uint32_t)bperm_i(lane >= off ? lane - off : lane, (int)incl);
-    if (lane >= off) incl += v;
-  }
-  if (active) { s_bps[lane] = pstart; s_boff[lane] = incl - npts; }
-  if (lane == 63) {
-    s_boff[kCapBricks] = incl;                              // total
-    if (!(incl < (uint32_t)kCapPts)) s_box[7] = 0;          // one slot is kept for the end-of-run sentinel
-  }
-}
-
-// A descriptor field read where it is used, through an index the optimiser cannot see through: otherwise two dozen
-// loop-invariant pointers and scalars are hoisted into SGPRs for the whole tile loop (the body then spilled them to VGPR lanes
-// and scratch).  The index is made uniform again (readfirstlane), so the reads stay scalar loads from the global segment.
-__device__ inline const PCM_GLOBAL PairDesc* opaque_desc(const PairDesc* dp) {
-  int z = 0;
-  asm volatile("" : "+v"(z));
-  return (const PCM_GLOBAL PairDesc*)dp + __builtin_amdgcn_readfirstlane(z);
-}
-#define PCM_DESC_FIELD(type, dp, field) ((type)opaque_desc(dp)->field)
-
-template <bool WRITE_PLANES, bool FUSED>
-__global__ void __launch_bounds__(256, 4) k_linearize_pipe(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp, LsqParams lp,
-                                                           unsigned char* __restrict__ flags_row) {
-  const int pair = __builtin_amdgcn_readfirstlane(PCM_PAIR_OF(kp, blockIdx.y));   // uniform: keep it (and the descriptor pointer) scalar
-  if (states[pair].mode != MODE_LINEARIZE) {
-    if constexpr (FUSED) {   // a pair that finished since the host last looked: its status byte of this round still has to land
-      if (blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(flags_row + pair, (unsigned char)(states[pair].mode != MODE_DONE ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-  const PairDesc* dp = descs + pair;
-  const uint32_t N = dp->src.num_points;
-  const uint32_t ntiles = (N + 255u) >> 8;
-  if (blockIdx.x >= ntiles) return;
-  const uint32_t gx = gridDim.x;
-  const float4* src_pts = dp->src.pts;
-  const float4* map_pts = dp->tgt.pts;
-  const float inv_res = dp->tgt.inv_res;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-  __shared__ __attribute__((aligned(16))) float s_pose[12];   // the float pose of the round (row-major 3 x 4): read where it is used, not held in SGPRs
-  __shared__ int s_red[4][6];
-  __shared__ int s_box[8];                 // box of the NEXT tile once S2 has run: origin xyz, dims xyz, ncell, fits
-  __shared__ int s_bbox[8];                // first brick xyz, brick dims xyz, nbricks
-  __shared__ int4 s_borg[kCapBricks];      // voxel coordinates of each brick's corner relative to the box origin
-  __shared__ uint32_t s_bps[kCapBricks];   // first map point of each brick under the box
-  __shared__ uint32_t s_boff[kCapBricks + 1];  // its offset in s_pts (exclusive scan of the point counts); [kCapBricks] = total
-  __shared__ uint32_t s_njobs;
-  __shared__ uint32_t s_last;
-  __shared__ uint16_t s_cell[kCapCells];   // first staged point of the voxel in that cell, kNoCell when empty
-  __shared__ float4 s_pts[kCapPts];        // the bricks' map points, .w = voxel tag; later the 256 x 8 residual rows
-  __shared__ uint32_t s_job[256];          // owner tid | m << 16
-  __shared__ uint32_t s_jobid[256][4];     // the 3 or 4 neighbour ids of the job; later the 8 x 32 group sums (doubles)
-
-  if (threadIdx.x < 12) {   // trans.cast<float>()  laser_mapping.cc:602-603
-    const int r = threadIdx.x >> 2, cc = threadIdx.x & 3;
-    s_pose[threadIdx.x] = (float)states[pair].x0[r * 4 + cc];
-  }
-  __syncthreads();
-  // pose of the round out of LDS (12 broadcast reads into short-lived VGPRs)
-  auto coords_of = [&](const float4& pt, bool lv) {
-    PoseF P;
-    uint32_t z = 0;
-    asm volatile("" : "+v"(z));   // opaque zero in the address: the 12 reads are not hoisted out of the tile loop
-    const float4 r0 = *reinterpret_cast<const float4*>(&s_pose[z]), r1 = *reinterpret_cast<const float4*>(&s_pose[z + 4]), r2 = *reinterpret_cast<const float4*>(&s_pose[z + 8]);
-    P.r[0] = r0.x; P.r[1] = r0.y; P.r[2] = r0.z; P.t[0] = r0.w;
-    P.r[3] = r1.x; P.r[4] = r1.y; P.r[5] = r1.z; P.t[1] = r1.w;
-    P.r[6] = r2.x; P.r[7] = r2.y; P.r[8] = r2.z; P.t[2] = r2.w;
-    return tile_coords(P, pt, lv, inv_res);
-  };
-
-  // ---- prologue: everything tile t0 needs, without overlap --------------------------------------------------------
-  uint32_t tile = blockIdx.x;
-  float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
-  {
-    const uint32_t i = tile * 256u + threadIdx.x;
-    if (i < N) p = gload4(src_pts + i);
-    const TileCoords c0 = coords_of(p, i < N);
-    wave_bounds(c0, s_red, lane, wave);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) tile_box(s_red, kp.use_lds != 0, s_box, s_bbox);
-  __syncthreads();
-  if (wave == 0) {
-    const BrickSlot* bricks = PCM_DESC_FIELD(const BrickSlot*, dp, tgt.bricks);
-    const uint32_t bmask_ = PCM_DESC_FIELD(uint32_t, dp, tgt.mask);
-    const ProbeState ps0 = probe_issue(bricks, bmask_, s_box, s_bbox, lane);
-    probe_resolve(bricks, bmask_, ps0, lane, s_box, s_bbox, s_borg, s_bps, s_boff);
-  }
-#pragma unroll
-  for (int j = 0; j < kCapCells / 256; j++) s_cell[threadIdx.x + 256 * j] = kNoCell;
-  __syncthreads();
-
-  // staged map points of the current tile, in registers until S1 writes them to LDS
-  float4 v[kCapPts / 256];
-  // scan point of the NEXT tile: loaded in S5 of the previous iteration for the bounds in S1, loaded again (L2-hot) in S5
-  // of this iteration as the next `p`, so that it does not occupy registers during the search
-  float4 pn = make_float4(0.f, 0.f, 0.f, 1.f);
-  // box of the current tile (uniform): origin, dims, staged total, LDS path or per-lane global probing
-  int ox0, oy0, oz0, Dx, Dy, Dz;
-  uint32_t total;
-  bool use_lds;
-#define PCM_PIPE_LOAD_STAGE(tid_)                                                                                 \
-  {                                                                                                             \
-    ox0 = __builtin_amdgcn_readfirstlane(s_box[0]); oy0 = __builtin_amdgcn_readfirstlane(s_box[1]);             \
-    oz0 = __builtin_amdgcn_readfirstlane(s_box[2]); Dx = __builtin_amdgcn_readfirstlane(s_box[3]);               \
-    Dy = __builtin_amdgcn_readfirstlane(s_box[4]); Dz = __builtin_amdgcn_readfirstlane(s_box[5]);                \
-    use_lds = __builtin_amdgcn_readfirstlane(s_box[7]) != 0;                                                    \
-    total = use_lds ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_boff[kCapBricks]) : 0u;                   \
-    const int nb_ = __builtin_amdgcn_readfirstlane(s_bbox[6]);                                                  \
-    _Pragma("unroll") for (int r = 0; r < kCapPts / 256; r++) {                                                 \
-      const uint32_t k = tid_ + 256u * r;                                                                       \
-      float4 t_ = make_float4(0.f, 0.f, 0.f, 0.f);   /* every element is (re)defined here: nothing of the old tile stays live */ \
-      if (k < total) {                                                                                          \
-        int b = 0;                                                                                              \
-        while (b + 1 < nb_ && s_boff[b + 1] <= k) b++;   /* nb is small (typically 1..8) */                     \
-        t_ = gload4(map_pts + s_bps[b] + (k - s_boff[b]));                                                      \
-      }                                                                                                         \
-      v[r] = t_;                                                                                                \
-    }                                                                                                           \
-  }
-  PCM_PIPE_LOAD_STAGE(threadIdx.x)
-  {
-    const uint32_t in = (tile + gx) * 256u + threadIdx.x;
-    if (tile + gx < ntiles && in < N) pn = gload4(src_pts + in);
-  }
-
-  // deferred arrival ticket of the previous tile (FUSED): 0 nothing pending, 1 row stored (ticket not taken), 2 ticket in flight
-  int tk_state = 0;
-  unsigned int tk_value = 0;
-  bool finish_now = false;
-
-  for (;;) {
-    // Per-iteration opaque copies of the thread index and of the neighbourhood size: without them the compiler hoists every
-    // thread-invariant address, shuffle index and the 27 `g < num_neighbors` lane masks out of this loop and keeps them in
-    // registers for the whole kernel (54 SGPRs for the masks alone; the body then spilled to VGPR lanes and scratch)
-    uint32_t tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    int nn = kp.num_neighbors;
-    asm volatile("" : "+s"(nn));
-    const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
-    const uint32_t i = tile * 256u + tid;
-    const bool live = i < N;
-    const bool has_next = tile + gx < ntiles;
-    // ---- S1: staged points -> LDS, voxel heads -> cell grid; bounds of the next tile --------------------------------
-    if (use_lds) {
-      const int nb_ = s_bbox[6];
-#pragma unroll
-      for (int r = 0; r < kCapPts / 256; r++) {
-        const uint32_t k = tid + 256u * r;
-        if (k < total) {
-          s_pts[k] = v[r];
-          const int tag = __float_as_int(v[r].w);
-          if (tag < 0) {
-            int b = 0;
-            while (b + 1 < nb_ && s_boff[b + 1] <= k) b++;
-            const int4 o = s_borg[b];
-            const int li = tag & 511;
-            const int x = o.x + (li >> 6), y = o.y + ((li >> 3) & 7), z = o.z + (li & 7);
-            if (x >= 0 && x < Dx && y >= 0 && y < Dy && z >= 0 && z < Dz) s_cell[(x * Dy + y) * Dz + z] = (uint16_t)k;
-          }
-        }
-      }
-      if (tid == 0) s_pts[total] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));   // end-of-run sentinel (a "head")
-    }
-    if (tid == 0) s_njobs = 0;
-    if (has_next) {
-      const uint32_t in = (tile + gx) * 256u + tid;
-      const TileCoords cn = coords_of(pn, in < N);
-      wave_bounds(cn, s_red, lane, wave);
-    }
-    if constexpr (FUSED) {
-      // ticket of the previous tile: its partial row was stored write-through at the end of the last iteration; this wave
-      // has just waited for its staging loads, so draining the queue (the row stores included) costs next to nothing
-      if (wave == 0 && tk_state == 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) tk_value = __hip_atomic_fetch_add((PCM_GLOBAL unsigned int*)PCM_DESC_FIELD(unsigned int*, dp, counter), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tk_state = 2;
-      }
-    }
-    __syncthreads();   // B1: s_box / s_borg / s_bps / s_boff of THIS tile are dead from here on (S2 and S4 rewrite them for the next)
-    // ---- S2: box + brick probes of the next tile (wave 0; the loads stay in flight during the search) ---------------
-    ProbeState ps;
-    ps.h = 0; ps.k0 = make_uint2(0, 0); ps.k1 = make_uint2(0, 0);
-    if (wave == 0 && has_next) {
-      if (tid == 0) tile_box(s_red, kp.use_lds != 0, s_box, s_bbox);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      ps = probe_issue(PCM_DESC_FIELD(const BrickSlot*, dp, tgt.bricks), PCM_DESC_FIELD(uint32_t, dp, tgt.mask), s_box, s_bbox, lane);
-    }
-    // ---- S3: 27-cell / 5-NN search out of LDS (reference cell order), plane fit -------------------------------------
-    const TileCoords c = coords_of(p, live);
-    Best best;
-    best_init(best, kp.max_range_sq);
-    if (use_lds) {
-      if (c.search) {
-        const int DyDz = Dy * Dz;
-        const int cell0 = ((c.cx - ox0) * Dy + (c.cy - oy0)) * Dz + (c.cz - oz0);
-        uint16_t kh[27];
-#pragma unroll
-        for (int g = 0; g < 27; g++) {
-          kh[g] = kNoCell;
-          if (g < nn) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
-        }
-        const char* pbase = reinterpret_cast<const char*>(s_pts);
-#pragma unroll
-        for (int g = 0; g < 27; g++) {
-          if (kh[g] != kNoCell) {
-            uint32_t off = (uint32_t)kh[g] << 4;
-            float4 mp = *reinterpret_cast<const float4*>(pbase + off);
-            const uint32_t off_end = total << 4;   // every wave leaves this loop: the run cannot pass the staged points
-            for (;;) {
-              const float4 nx = *reinterpret_cast<const float4*>(pbase + off + 16);
-              best_offer(best, mp, c.q, off, kp.max_range_sq);
-              if (__float_as_int(nx.w) < 0 || off + 16 >= off_end) break;   // the next staged point opens another voxel (or is the sentinel)
-              mp = nx;
-              off += 16;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < K; j++) best.i[j] >>= 4;
-      }
-    } else if (c.search) {
-      TargetView tg;
-      tg.pts = map_pts;
-      tg.vox_start = PCM_DESC_FIELD(const uint32_t*, dp, tgt.vox_start);
-      tg.bricks = PCM_DESC_FIELD(const BrickSlot*, dp, tgt.bricks);
-      tg.bmask = PCM_DESC_FIELD(const uint32_t*, dp, tgt.bmask);
-      tg.bpref = PCM_DESC_FIELD(const uint16_t*, dp, tgt.bpref);
-      tg.gvox = nullptr;
-      tg.mask = PCM_DESC_FIELD(uint32_t, dp, tgt.mask);
-      tg.num_points = 0; tg.inv_res = inv_res; tg.res = 0.f;
-      uint32_t n_cand = 0, n_probe = 0;
-      knn_global<false>(tg, c.q, c.cx, c.cy, c.cz, nn, kp.max_range_sq, best, n_cand, n_probe);
-    }
-    best_finish(best);
-    float4 pl = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
-    uint32_t my_job = ~0u;
-    if (live) {
-      if (best.m == K) {
-        float px[K], py[K], pz[K];
-#pragma unroll
-        for (int j = 0; j < K; j++) {
-          const float4 mp = use_lds ? s_pts[best.i[j]] : gload4(map_pts + best.i[j]);
-          px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
-        }
-        float4 fit;
-        if (esti_plane(px, py, pz, K, kp.plane_threshold, &fit)) pl = fit;
-      } else if (best.m >= KMIN) {
-        my_job = atomicAdd(&s_njobs, 1u);
-        s_job[my_job] = tid | ((uint32_t)best.m << 16);
-#pragma unroll
-        for (int j = 0; j < 4; j++) s_jobid[my_job][j] = best.i[j];
-      }
-    }
-    __syncthreads();   // B2
-    {
-      const uint32_t njobs = s_njobs;
-      for (uint32_t job = tid; job < njobs; job += 256) {
-        const uint32_t m = s_job[job] >> 16;
-        float px[K], py[K], pz[K];
-#pragma unroll
-        for (int j = 0; j < K; j++) {
-          float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j < (int)m) mp = use_lds ? s_pts[s_jobid[job][j]] : gload4(map_pts + s_jobid[job][j]);
-          px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
-        }
-        float4 fit;
-        if (!esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) fit.x = __builtin_nanf("");
-        s_jobid[job][0] = __float_as_uint(fit.x); s_jobid[job][1] = __float_as_uint(fit.y);   // hand the plane back to its owner lane
-        s_jobid[job][2] = __float_as_uint(fit.z); s_jobid[job][3] = __float_as_uint(fit.w);
-      }
-    }
-    __syncthreads();   // B3: nobody reads s_pts / s_cell of this tile after this point
-    if (my_job != ~0u) pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
-    // ---- S4: brick list of the next tile (wave 0), cell grid cleared, residual row of this tile -> LDS ----------------
-    if (wave == 0) {
-      if (has_next) probe_resolve(PCM_DESC_FIELD(const BrickSlot*, dp, tgt.bricks), PCM_DESC_FIELD(uint32_t, dp, tgt.mask), ps, lane, s_box, s_bbox, s_borg, s_bps, s_boff);
-      if constexpr (FUSED) {
-        if (tid == 0) {
-          unsigned int last = 0u;
-          if (tk_state == 2 && tk_value == ntiles - 1u) {
-            last = 1u;
-            __hip_atomic_store((PCM_GLOBAL unsigned int*)PCM_DESC_FIELD(unsigned int*, dp, counter), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next round's launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          s_last = last;
-        }
-        if (tk_state == 2) tk_state = 0;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < kCapCells / 256; j++) s_cell[tid + 256 * j] = kNoCell;
-    float* s_row = reinterpret_cast<float*>(s_pts);                       // [256][8]: J0..J5, e, selected
-    double* s_grp = reinterpret_cast<double*>(&s_jobid[0][0]);            // [8][32] group partials (s_jobid is free: written after B4, its planes were read back above)
-    {
-      float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (live) {
-        bool sel = !(pl.x != pl.x);
-        if (sel) {
-          const float pd2 = pl.x * c.q[0] + pl.y * c.q[1] + pl.z * c.q[2] + pl.w;  // laser_mapping.cc:627-629
-          const float pnorm = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
-          sel = pnorm > 81.f * pd2 * pd2;                                      // :631
-          if (sel) {
-            // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
-            row[0] = c.q[1] * pl.z - c.q[2] * pl.y;
-            row[1] = c.q[2] * pl.x - c.q[0] * pl.z;
-            row[2] = c.q[0] * pl.y - c.q[1] * pl.x;
-            row[3] = pl.x; row[4] = pl.y; row[5] = pl.z;
-            row[6] = pd2;
-            row[7] = 1.f;
-          }
-        }
-        if (WRITE_PLANES) gstore4(PCM_DESC_FIELD(float4*, dp, planes) + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
-      }
-      float4* dst = reinterpret_cast<float4*>(s_row + tid * 8);
-      dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-      dst[1] = make_float4(row[4], row[5], row[6], row[7]);
-    }
-    __syncthreads();   // B4
-    // ---- S5: loads of the next tile issued (map points -> registers, its scan point, the scan point of the tile after it); 29 sums, part 1 ---
-    if constexpr (FUSED) finish_now = s_last != 0;
-    p = make_float4(0.f, 0.f, 0.f, 1.f);
-    pn = make_float4(0.f, 0.f, 0.f, 1.f);
-    if (has_next) {
-      PCM_PIPE_LOAD_STAGE(tid)
-      const uint32_t in1 = (tile + gx) * 256u + tid, in2 = (tile + 2u * gx) * 256u + tid;
-      if (in1 < N) p = gload4(src_pts + in1);
-      if (tile + 2u * gx < ntiles && in2 < N) pn = gload4(src_pts + in2);
-    } else {
-      total = 0u; use_lds = false;
-#pragma unroll
-      for (int r = 0; r < kCapPts / 256; r++) v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    {
-      // term j = row[ia] * row[ib]: 21 x H upper triangle, 6 x b = J e, cost = e e, count = sel sel; thread (group g, term j) adds 32 rows in double
-      const int j = tid & 31, g = tid >> 5;
-      double sum = 0.0;
-      if (j < kNumSums) {
-        const int ia = c_term_a[j], ib = c_term_b[j];
-        const float* r0 = s_row + (g * 32) * 8;
-#pragma unroll 8
-        for (int k = 0; k < 32; k++) sum = fma((double)r0[k * 8 + ia], (double)r0[k * 8 + ib], sum);
-      }
-      s_grp[g * kPartialStride + j] = sum;
-    }
-    __syncthreads();   // B5
-    // ---- S6: the tile's partial row ---------------------------------------------------------------------------------------
-    if (tid < kNumSums) {
-      double sum = 0.0;
-#pragma unroll
-      for (int g = 0; g < 8; g++) sum += s_grp[g * kPartialStride + tid];
-      double* prow = PCM_DESC_FIELD(double*, dp, partials) + (size_t)tile * kPartialStride + tid;
-      if constexpr (FUSED) gstore_d_wt(prow, sum);
-      else gstore_d(prow, sum);
-    }
-    if constexpr (FUSED) {
-      if (finish_now) {   // this workgroup took the pair's last ticket (for its previous tile): sum the rows, take the GN step
-        // s_pts is free here (the next tile's points are still in registers); s_grp (in s_jobid) is still being read by wave 0
-        double* f_grp = reinterpret_cast<double*>(s_pts);
-        double* f_tot = f_grp + 32 * kPartialStride;
-        __syncthreads();
-        finish_pair_in_place(*dp, const_cast<PairState*>(states), pair, lp, (int)ntiles, flags_row, f_grp, f_tot);
-        __syncthreads();
-        finish_now = false;
-      }
-      if (wave == 0) tk_state = 1;
-    }
-    if (!has_next) break;
-    tile += gx;
-  }
-#undef PCM_PIPE_LOAD_STAGE
-  if constexpr (FUSED) {
-    // ticket of the workgroup's last tile: the one wait that nothing hides
-    if (wave == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (threadIdx.x == 0) {
-        unsigned int* counter = PCM_DESC_FIELD(unsigned int*, dp, counter);
-        const unsigned int t = __hip_atomic_fetch_add((PCM_GLOBAL unsigned int*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned int last = 0u;
-        if (t == ntiles - 1u) {
-          last = 1u;
-          __hip_atomic_store((PCM_GLOBAL unsigned int*)counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_last = last;
-      }
-    }
-    __syncthreads();
-    if (s_last) {
-      double* f_grp = reinterpret_cast<double*>(s_pts);
-      double* f_tot = f_grp + 32 * kPartialStride;
-      finish_pair_in_place(*dp, const_cast<PairState*>(states), pair, lp, (int)ntiles, flags_row, f_grp, f_tot);
-    }
-  }
-}
-
-// grid.x of the pipelined kernel: one generation of workgroups (4 per CU x 256 CUs) over the pairs launched, each walking
-// ceil(tiles / gx) tiles; late rounds with few pairs fall back to one tile per workgroup (nothing to overlap, but no idle CU)
-static inline unsigned pipe_grid_x(int tiles_per_pair, int npairs, int deep) {
-  if (deep) return (unsigned)(tiles_per_pair >= 4 ? tiles_per_pair / 4 : 1);
-  static const int forced_tiles = [] { const char* e = getenv("PCM_PIPE_TILES"); return e ? atoi(e) : 0; }();   // tuning knob: tiles per workgroup
-  if (forced_tiles > 0) return (unsigned)((tiles_per_pair + forced_tiles - 1) / forced_tiles);
-  const long total = (long)tiles_per_pair * npairs;
-  if (total <= 1024 || npairs >= 1024) return (unsigned)tiles_per_pair;
-  const int gx = 1024 / npairs;
-  return (unsigned)(gx < tiles_per_pair ? gx : tiles_per_pair);
-}
-
-void launch_linearize_pipe(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool write_planes, bool fused,
-                           unsigned char* d_flags_row) {
-  dim3 grid(pipe_grid_x(kp.tiles_per_pair, npairs, kp.pipe_deep), (unsigned)npairs);
-  if (fused) k_linearize_pipe<false, true><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, lp, d_flags_row);
-  else if (write_planes) k_linearize_pipe<true, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, lp, d_flags_row);
-  else k_linearize_pipe<false, false><<<grid, 256, 0, stream>>>(d_descs, d_states, kp, lp, d_flags_row);
 }
 
 // GN rounds with very few live pairs: the search kernel's last workgroup per pair also takes the step (no k_finish_round launch)

@@ -19,7 +19,9 @@
 
 namespace pcm {
 
-enum PairMode : int32_t { MODE_LINEARIZE = 0, MODE_TRIAL = 1, MODE_DONE = 2, MODE_WAIT = 3 };   // WAIT: queued behind the batch window
+enum PairMode : int32_t { MODE_LINEARIZE = 0, MODE_TRIAL = 1, MODE_DONE = 2, MODE_WAIT = 3, MODE_PENDING = 4 };
+// WAIT: queued behind the batch window; PENDING: handed a slot by a pair that finished in this launch, promoted to LINEARIZE by
+// its OWN workgroup of the next step launch (never activated inside the launch that other workgroups are still reading)
 
 // Per-pair optimiser state, resident in device memory for the whole align().
 struct PairState {

@@ -65,6 +65,9 @@ int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, i
   w.device = c->device;
   if (npairs > w.cap_pairs) {
     if (w.d_descs) { hipFree(w.d_descs); hipFree(w.d_states); hipFree(w.d_guesses); hipFree(w.d_results); hipFree(w.d_sums); hipFree(w.d_jobs); }
+    // a failed hipMalloc below returns at once (HIPCK): nothing freed here may stay reachable, or a retry / pcm_destroy frees it twice
+    w.d_descs = nullptr; w.d_states = nullptr; w.d_guesses = nullptr; w.d_results = nullptr; w.d_sums = nullptr; w.d_jobs = nullptr;
+    w.cap_pairs = 0;
     const int cap = std::max(npairs, 64);
     HIPCK(c, hipMalloc(&w.d_descs, sizeof(PairDesc) * cap));
     HIPCK(c, hipMalloc(&w.d_states, sizeof(PairState) * cap));
@@ -76,6 +79,7 @@ int ensure_ws(pcm_ctx* c, Workspace** out, int npairs, size_t partial_doubles, i
   }
   if (partial_doubles > w.cap_partials) {
     if (w.d_partials) hipFree(w.d_partials);
+    w.d_partials = nullptr; w.cap_partials = 0;
     HIPCK(c, hipMalloc(&w.d_partials, sizeof(double) * partial_doubles));
     w.cap_partials = partial_doubles;
   }
@@ -394,7 +398,6 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.points_per_block = geom.points_per_block;
   kp.tiles_per_pair = geom.tiles_per_pair;
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
-  kp.pipe_deep = (g.flags & PCM_FLAG_PIPE_DEEP) ? 1 : 0;
   kp.do_step = 1;
   kp.lin_points_per_block = (is_ndt(g.model) || g.model == PCM_MODEL_VGICP_CUDA) ? geom.points_per_block : 256;
   kp.coord_mode = coord_mode_for(g.model);
@@ -478,7 +481,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   // device (k_finish_round) -- the late rounds of a slow pair then overlap the early rounds of its successors
   const int window = (g.batch_window > 0 && g.max_iterations > 0) ? std::min(n, g.batch_window) : n;
   const int per_pair_rounds = std::max(1, g.max_iterations) * (g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT ? 1 + std::max(1, g.lm_max_iterations) : 1);
-  const int max_rounds = per_pair_rounds * (n - window + 1) + 1;
+  const int max_rounds = per_pair_rounds * (n - window + 1) + 1 + 2 * (n - window);   // + the rounds a handed-over pair spends PENDING
   const size_t per_pair_partials = (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride;
   Workspace* w = nullptr;
   int rc = ensure_ws(c0, &w, n, per_pair_partials * n, max_rounds);
@@ -540,13 +543,12 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
     // GN: the last workgroup of a pair's search launch takes its step (write-through hand-off of the partial rows, kernels.hip);
     // PCM_FLAG_SEPARATE_STEP keeps the second launch (k_finish_round) for A/B runs and the bit-equality test
-    const bool fuse = use_list && !is_lm && !ndt && !gicp && !counters_on && !timing_on && kp.do_step && (g.flags & PCM_FLAG_FUSED_STEP) && !(g.flags & PCM_FLAG_SEPARATE_STEP);
-    // PCM_FLAG_PIPE_KERNEL: the pipelined search kernel (several tiles per workgroup, next tile's loads under this tile's
-    // arithmetic; bit-identical results).  Measured SLOWER than one tile per workgroup at every depth
-    const bool pipe = use_list && !ndt && !gicp && !counters_on && !timing_on && (g.flags & PCM_FLAG_PIPE_KERNEL);
+    // PCM_FLAG_FUSED_STEP (off by default): the last workgroup of a pair's search launch takes the GN step (write-through hand-off of
+    // the partial rows, kernels.hip).  Measured slower than the second launch at every round size, the single-pair rounds
+    // included (profiles/r02_fused_step_threshold_sweep.txt): every workgroup pays a store drain and a returned atomic.
+    const bool fuse = use_list && !is_lm && !ndt && !gicp && !counters_on && !timing_on && kp.do_step && (g.flags & PCM_FLAG_FUSED_STEP);
     if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), false);
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
-    else if (pipe) launch_linearize_pipe(st, w->d_descs, w->d_states, kpr, lp, nl, write_sel, fuse, w->d_flags + (size_t)r * n);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
@@ -571,7 +573,9 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
         unsigned spins = 0;
         while (row[i] == 0) {   // the round's status byte of pair i has not landed yet
           if ((++spins & 0xfff) == 0) {
-            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) { c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
+            // on both error returns the queued kernels may still be writing into the workspace and h_flags: drain the stream
+            // first, so that the caller can destroy the context safely
+            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) { (void)hipStreamSynchronize(st); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
             if (hipStreamQuery(st) == hipSuccess && row[i] == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
           }
         }
@@ -648,7 +652,6 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
   if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, ndt_kind(c->cfg.model), !linearize);
   else if (is_gicp(c->cfg.model)) launch_gicp(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_VGICP, !linearize);
-  else if (linearize && (c->cfg.flags & PCM_FLAG_PIPE_KERNEL)) launch_linearize_pipe(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, true, false, w->d_flags);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
   launch_finish_round(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, !linearize, false, w->d_flags, w->d_sums);

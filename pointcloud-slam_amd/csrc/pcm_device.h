@@ -229,7 +229,6 @@ struct KernelParams {
   int32_t lio_extrinsic;      // LIO: extrinsic_est_en (columns 6..11 of h_x)
   int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)
   int32_t coord_mode;         // CoordMode of the target map (GICP / VGICP kernels)
-  int32_t pipe_deep;          // test knob: at least four tiles per workgroup of the pipelined kernel whatever the load
   int32_t use_list;           // 1: the grid's pair axis indexes `active` (only pairs the host still believes active are launched)
   uint8_t active[64];         // pair index of each grid entry (batches of <= 64 pairs)
   double max_corr_sq;         // GICP: corr_dist_threshold_^2 (double, as pcl::Registration holds it)

@@ -97,8 +97,6 @@ struct LaunchGeom {
 };
 void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                       unsigned long long* d_stats, bool timing);
-void launch_linearize_pipe(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool write_planes, bool fused,
-                           unsigned char* d_flags_row);
 void launch_linearize_fused(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, unsigned char* d_flags_row);
 void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp);
 void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out);

@@ -23,6 +23,73 @@ def pair_ids_for_rank(pairs_per_rank: int, rank: int) -> list:
     return [rank * pairs_per_rank + i for i in range(pairs_per_rank)]
 
 
+def run_pipelined_steps(k: int, n_slots: int, sub_step, gather=None, stagger_s: float = 0.0, on_thread_start=None):
+    """k passes over every pipeline slot of this rank; returns the last result of every slot.
+
+    ``sub_step(j, wait_prev)`` runs one pass of slot j on the caller's stream of that slot and returns when the slot's result
+    block is complete; it must call ``wait_prev()`` (when not None) before it overwrites the block of its previous pass.
+    ``gather(j)`` (None on a single rank) performs the collective for slot j's block and returns when it has completed.
+
+    The slots are driven by one host thread each, so their compute overlaps.  Every collective is issued by ONE further thread in
+    the order (step, slot) -- identical on every rank by construction, on ONE communicator: ranks may finish their slots in any
+    order without the collectives ever being enqueued in different orders (the hazard of one communicator per slot thread).
+    """
+    import threading
+    import time
+    last = [None] * n_slots
+    errs = []
+    done = [[threading.Event() for _ in range(n_slots)] for _ in range(k)] if gather else None       # (step, slot) finished its pass
+    gathered = [[threading.Event() for _ in range(n_slots)] for _ in range(k)] if gather else None   # ... and its block has been gathered
+
+    def worker(j):
+        try:
+            if on_thread_start:
+                on_thread_start()
+            if stagger_s > 0 and j > 0:
+                time.sleep(j * stagger_s)
+            for step in range(k):
+                wait_prev = (lambda st=step: gathered[st - 1][j].wait()) if (gather and step > 0) else None
+                last[j] = sub_step(j, wait_prev)
+                if gather:
+                    done[step][j].set()
+        except Exception as e:   # surfaced in the calling thread
+            errs.append(e)
+            if gather:
+                for row in done:
+                    row[j].set()
+
+    def comm_worker():
+        try:
+            if on_thread_start:
+                on_thread_start()
+            for step in range(k):
+                for j in range(n_slots):
+                    done[step][j].wait()
+                    if errs:
+                        return
+                    gather(j)
+                    gathered[step][j].set()
+        except Exception as e:
+            errs.append(e)
+        finally:
+            for row in gathered:
+                for ev in row:
+                    ev.set()
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_slots)] if (n_slots > 1 or gather) else []
+    if gather:
+        ths.append(threading.Thread(target=comm_worker))
+    if not ths:
+        worker(0)
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    if errs:
+        raise errs[0]
+    return last
+
+
 def split_sub_batches(n_local: int, n_slots: int) -> list:
     """Contiguous sub-batches of a rank's pairs (one per pipeline slot / stream)."""
     n_slots = max(1, min(n_slots, n_local))

@@ -303,31 +303,20 @@ def test_fused_step_equals_separate_step(pcm, synth):
 
 
 @pytest.mark.gpu
-def test_pipelined_kernel_equals_one_tile_kernel(pcm, synth):
-    """The pipelined search kernel (several tiles per workgroup, next tile's loads issued under this tile's arithmetic;
-    flag 16 forces >= 4 tiles per workgroup on these small clouds) computes the same per-tile sums in the same order as the
-    default one-tile-per-workgroup kernel (the pipelined one is PCM_FLAG_PIPE_KERNEL = 8): poses, iteration counts and the normal equations of the
-    parity hook are bit-identical, with the step in a second launch or in the last workgroup (PCM_FLAG_FUSED_STEP = 2),
-    GN and LM, ragged batch, 7 / 27 cells."""
-    pairs = [synth.make_pair(60 + i, 3000 + 1700 * i, 30000 + 9000 * i) for i in range(6)]
-    guesses = np.stack([p.guess for p in pairs])
-    for opt in ("GN", "LM"):
-        for nn in (27, 7):
-            out = {}
-            for flags in (0, 8, 8 | 16, 8 | 16 | 2, 8 | 2):
-                regs = []
-                for p in pairs:
-                    g = pcm.P2PlaneRegistration(0, optimizer=opt, num_neighbors=nn, flags=flags)
-                    g.set_input_target(p.submap); g.set_input_source(p.scan); regs.append(g)
-                res = pcm.align_batch(regs, guesses)
-                lin = [regs[k].evaluate_cost(res[k].T64) for k in (0, 3)]
-                out[flags] = (res, lin)
-            ref, ref_lin = out[0]
-            for flags in (8, 8 | 16, 8 | 16 | 2, 8 | 2):
-                res, lin = out[flags]
-                for a, b in zip(ref, res):
-                    assert np.array_equal(a.T64, b.T64), (opt, nn, flags)
-                    assert a.iterations == b.iterations and a.num_inliers == b.num_inliers and a.num_linearize == b.num_linearize
-                    assert a.converged == b.converged
-                for (ca, Ha, ba, ia), (cb, Hb, bb, ib) in zip(ref_lin, lin):
-                    assert np.array_equal(Ha, Hb) and np.array_equal(ba, bb) and ca == cb and ia == ib
+def test_batch_window_hand_off_with_more_pairs_than_resident_workgroups(pcm, synth):
+    """700 small pairs, 5 at a time: the step launch has more workgroups than the device keeps resident at once, so a queued
+    pair's workgroup can run AFTER the pair that finished has handed it the slot in the same launch.  The hand-off only marks
+    the pair PENDING (its own workgroup promotes it in a later launch), so every pair still gets the result it gets alone."""
+    base = [synth.make_pair(90 + i, 600 + 50 * i, 6000 + 500 * i) for i in range(7)]
+    n = 700
+    regs, guesses = [], []
+    for k in range(n):
+        p = base[k % len(base)]
+        g = pcm.P2PlaneRegistration(0, optimizer="GN", batch_window=5, max_iterations=12)
+        g.set_input_target(p.submap); g.set_input_source(p.scan)
+        regs.append(g); guesses.append(p.guess)
+    batch = pcm.align_batch(regs, np.stack(guesses))
+    singles = [regs[k].align(base[k].guess) for k in range(len(base))]
+    for k in range(n):
+        s, b = singles[k % len(base)], batch[k]
+        assert np.array_equal(s.T64, b.T64) and s.iterations == b.iterations and s.num_linearize == b.num_linearize, k

@@ -1,6 +1,6 @@
-"""CPU test of the N>1 path: world_size-2 gloo processes shard the pairs, pack their
-result records and all-gather them exactly as bench.py does with RCCL (same code:
-pointcloud-slam_amd/sharding.py), one process group per pipeline slot."""
+"""CPU tests of the N>1 path with gloo: the ranks shard the pairs, pack their result records and all-gather them with the
+code bench.py runs with RCCL (pointcloud-slam_amd/sharding.py) -- including its control flow: one host thread per pipeline
+slot for the compute, ONE communicator, and ONE thread that issues every collective in (step, slot) order."""
 import os
 import socket
 import sys
@@ -28,15 +28,14 @@ def _worker(rank, world, port, pairs_per_rank, slots, q):
     sh = pcm.sharding
     ids = sh.pair_ids_for_rank(pairs_per_rank, rank)
     groups = sh.split_sub_batches(pairs_per_rank, slots)
-    pgs = [dist.new_group(list(range(world))) for _ in groups]
     gathered = np.zeros((world, pairs_per_rank * sh.RECORD_BYTES), np.uint8)
-    for grp, pg in zip(groups, pgs):
+    for grp in groups:
         res = []
         for i in grp:
             T = np.eye(4); T[:3, 3] = [ids[i], rank, 0.5]
             res.append({"T64": T, "iterations": ids[i] % 7, "converged": 1, "num_inliers": 1000 + ids[i]})
         local = torch.from_numpy(sh.pack_results(res))
-        got = sh.gather_records(local, world, group=pg).numpy()
+        got = sh.gather_records(local, world).numpy()
         lo, hi = grp[0] * sh.RECORD_BYTES, (grp[-1] + 1) * sh.RECORD_BYTES
         gathered[:, lo:hi] = got
     out = [sh.records_to_results(gathered[r]) for r in range(world)]
@@ -44,6 +43,83 @@ def _worker(rank, world, port, pairs_per_rank, slots, q):
     q.put((rank, summary))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _pipeline_worker(rank, world, port, pairs_per_rank, slots, steps, q):
+    """bench.py's N>1 control flow (sharding.run_pipelined_steps) with random per-rank, per-slot delays in place of the GPU work:
+    ranks finish their slots in different orders, the collectives must still pair up and every block must arrive intact."""
+    import random
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pointcloud_slam_amd as pcm
+    sh = pcm.sharding
+    ids = sh.pair_ids_for_rank(pairs_per_rank, rank)
+    groups = sh.split_sub_batches(pairs_per_rank, slots)
+    S = len(groups)
+    rec = sh.RECORD_BYTES
+    results = torch.zeros(pairs_per_rank * rec, dtype=torch.uint8)
+    gathered = torch.zeros(world, pairs_per_rank * rec, dtype=torch.uint8)
+    rng = random.Random(1000 * rank + 17)
+    step_of = [0] * S
+    log = []
+
+    def sub_step(j, wait_prev):
+        time.sleep(rng.uniform(0.0, 0.03) * (1 + (rank + j) % 3))     # uneven "compute": rank- and slot-dependent
+        if wait_prev is not None:
+            wait_prev()
+        res = []
+        for i in groups[j]:
+            T = np.eye(4); T[:3, 3] = [ids[i], rank, step_of[j]]
+            res.append({"T64": T, "iterations": step_of[j], "converged": 1, "num_inliers": 1000 + ids[i]})
+        lo, hi = groups[j][0] * rec, (groups[j][-1] + 1) * rec
+        results[lo:hi] = torch.from_numpy(sh.pack_results(res))
+        step_of[j] += 1
+        return step_of[j]
+
+    def gather(j):
+        lo, hi = groups[j][0] * rec, (groups[j][-1] + 1) * rec
+        got = sh.gather_records(results[lo:hi].clone(), world)
+        gathered[:, lo:hi] = got
+        rows = [sh.records_to_results(got[r].numpy()) for r in range(world)]
+        log.append((j, [row[0]["iterations"] for row in rows]))    # the step every rank's block of this collective belongs to
+
+    last = sh.run_pipelined_steps(steps, S, sub_step, gather, stagger_s=0.01 * (rank % 2))
+    assert last == [steps] * S
+    out = [sh.records_to_results(gathered[r].numpy()) for r in range(world)]
+    summary = [[(round(float(x["T64"][0, 3])), round(float(x["T64"][2, 3])), x["num_inliers"]) for x in row] for row in out]
+    q.put((rank, summary, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,slots", [(2, 2), (3, 3), (4, 2)])
+def test_pipelined_steps_with_uneven_ranks_gloo(world, slots):
+    ppr, steps = 6, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, ppr, slots, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, summary, log = q.get(timeout=180)
+        got[rank] = (summary, log)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [[(r * ppr + i, steps - 1, 1000 + r * ppr + i) for i in range(ppr)] for r in range(world)]   # the last step's blocks of every rank
+    nslots = len([1 for _ in range(min(slots, ppr))])
+    for rank in range(world):
+        summary, log = got[rank]
+        assert summary == want
+        # every collective matched blocks of the SAME (step, slot) on all ranks, in (step, slot) order
+        assert [j for j, _ in log] == [j for _ in range(steps) for j in range(nslots)]
+        for n, (j, steps_seen) in enumerate(log):
+            assert steps_seen == [n // nslots] * world
 
 
 @pytest.mark.parametrize("slots", [1, 2])
