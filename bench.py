@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--sort-source", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--slot-priority", type=int, default=0, help="1: the pipeline slots run on streams of descending priority (slot 0 highest), so the "
+                    "tail rounds of one slot are not queued behind the bulk of another")
     ap.add_argument("--stagger", type=float, default=0.5, help="start offset between the pipeline slots, in units of one warm pass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured path); gloo only to rehearse the N>1 control flow with several ranks sharing one GPU")
@@ -177,6 +179,14 @@ def main():
     from pointcloud_slam_amd import sharding
     groups = sharding.split_sub_batches(n_local, args.pipeline)
     S = len(groups)
+    slot_streams = []
+    if args.slot_priority:
+        lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        for j in range(S):
+            st_j = torch.cuda.Stream(device=dev, priority=(hi_p if j == 0 else lo_p))
+            slot_streams.append(st_j)
+            for i in groups[j]:
+                regs[i].set_stream(st_j.cuda_stream)
     # ONE communicator (the default group) and ONE thread that issues every collective, in the order (step, slot) -- the same on
     # every rank by construction.  (Round 1 gave each pipeline slot its own communicator and let the slot threads issue their
     # gathers as they finished: rank A could enqueue slot 0 then 1 while rank B enqueued 1 then 0, the documented way to hang

@@ -262,37 +262,55 @@ __device__ inline void finish_pair_in_place(const PairDesc& d, PairState* states
   }
 }
 
-__global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restrict__ descs, PairState* __restrict__ states, KernelParams kp, LsqParams lp, int trial_round,
-                                                       int write_flags, unsigned char* __restrict__ flags_row, double* __restrict__ sums_out, unsigned int* __restrict__ queue,
-                                                       int npairs) {
+__global__ void __launch_bounds__(256) k_finish_round(const PairDesc* __restrict__ descs, PairState* __restrict__ states, KernelParams kp, LsqParams lp, int trial_round,
+                                                      int write_flags, unsigned char* __restrict__ flags_row, double* __restrict__ sums_out, unsigned int* __restrict__ queue,
+                                                      int npairs) {
+  // 256 threads, 4.2 KB of LDS: with several batches in flight this launch has to find room on CUs that another stream's search
+  // kernel fills (4 x 39.6 KB of LDS, 448 of 512 VGPRs per SIMD).  The 1024-thread / 8.5 KB form of round 1 needed three of the four
+  // resident search workgroups of one CU to retire at once and averaged 41 us under the two-slot schedule (13 us alone); this one
+  // fits as soon as ONE of them retires.  Same sums in the same order: 32 row groups of stride 32, each summed in row order, then
+  // the group totals added in group order.
   const int pair = PCM_PAIR_OF(kp, blockIdx.x);
   const int mode = states[pair].mode;
   // batch window: a pair that was handed a slot (PENDING) starts with the NEXT round; only its own workgroup changes its mode here
   if (mode == MODE_PENDING && !trial_round && threadIdx.x == 0) states[pair].mode = MODE_LINEARIZE;
   if (mode == (trial_round ? MODE_TRIAL : MODE_LINEARIZE)) {
-    __shared__ double s_grp[32 * kPartialStride];
+    __shared__ double s_grp[16 * kPartialStride];
     __shared__ double s_tot[kPartialStride];
     const PairDesc d = descs[pair];
     const uint32_t per = (uint32_t)(trial_round ? kp.points_per_block : kp.lin_points_per_block);
     const int nblocks = (int)((d.src.num_points + per - 1u) / per);
-    const int j = threadIdx.x & 31, r = threadIdx.x >> 5;
-    double v = 0.0;
-    if (j < kNumSums) {
-      int b = r;
-      for (; b + 96 < nblocks; b += 128) {   // 4 independent loads in flight
-        const double v0 = gload_d(d.partials + (size_t)b * kPartialStride + j), v1 = gload_d(d.partials + (size_t)(b + 32) * kPartialStride + j),
-                     v2 = gload_d(d.partials + (size_t)(b + 64) * kPartialStride + j), v3 = gload_d(d.partials + (size_t)(b + 96) * kPartialStride + j);
-        v = (((v + v0) + v1) + v2) + v3;
+    const int j = threadIdx.x & 31, g8 = threadIdx.x >> 5;
+    double v[4];
+    // canonical partition: group r (0..31) = rows r, r + 32, r + 64, ...; thread (g8, j) sums groups r = g8 + 8q, q = 0..3
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = g8 + 8 * q;
+      double acc = 0.0;
+      if (j < kNumSums) {
+        int b = r;
+        for (; b + 96 < nblocks; b += 128) {   // 4 independent loads in flight
+          const double v0 = gload_d(d.partials + (size_t)b * kPartialStride + j), v1 = gload_d(d.partials + (size_t)(b + 32) * kPartialStride + j),
+                       v2 = gload_d(d.partials + (size_t)(b + 64) * kPartialStride + j), v3 = gload_d(d.partials + (size_t)(b + 96) * kPartialStride + j);
+          acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; b < nblocks; b += 32) acc += gload_d(d.partials + (size_t)b * kPartialStride + j);
       }
-      for (; b < nblocks; b += 32) v += gload_d(d.partials + (size_t)b * kPartialStride + j);
+      v[q] = acc;
     }
-    s_grp[r * kPartialStride + j] = v;
-    __syncthreads();
-    if (threadIdx.x < kNumSums) {
-      double t = 0.0;
-      for (int k = 0; k < 32; k++) t += s_grp[k * kPartialStride + threadIdx.x];
-      s_tot[threadIdx.x] = t;
+    // group totals added in group order, 16 groups at a time through 4 KB of LDS
+    double t = 0.0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      s_grp[(g8) * kPartialStride + j] = v[2 * half];            // groups 16 * half + g8
+      s_grp[(g8 + 8) * kPartialStride + j] = v[2 * half + 1];    // groups 16 * half + 8 + g8
+      __syncthreads();
+      if (threadIdx.x < kNumSums) {
+        for (int k = 0; k < 16; k++) t += s_grp[k * kPartialStride + threadIdx.x];
+      }
+      __syncthreads();
     }
+    if (threadIdx.x < kNumSums) s_tot[threadIdx.x] = t;
     __syncthreads();
     if (threadIdx.x == 0) {
       if (kp.do_step) {
@@ -324,7 +342,7 @@ __global__ void __launch_bounds__(1024) k_finish_round(const PairDesc* __restric
 
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
                          bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue, int total_pairs) {
-  k_finish_round<<<npairs, 1024, 0, stream>>>(d_descs, d_states, kp, lp, trial_round ? 1 : 0, write_flags ? 1 : 0, d_flags_row, d_sums, d_queue, total_pairs > 0 ? total_pairs : npairs);
+  k_finish_round<<<npairs, 256, 0, stream>>>(d_descs, d_states, kp, lp, trial_round ? 1 : 0, write_flags ? 1 : 0, d_flags_row, d_sums, d_queue, total_pairs > 0 ? total_pairs : npairs);
 }
 
 // ---------------------------------------------------------------------------

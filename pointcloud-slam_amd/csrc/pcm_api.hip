@@ -481,7 +481,13 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   // device (k_finish_round) -- the late rounds of a slow pair then overlap the early rounds of its successors
   const int window = (g.batch_window > 0 && g.max_iterations > 0) ? std::min(n, g.batch_window) : n;
   const int per_pair_rounds = std::max(1, g.max_iterations) * (g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT ? 1 + std::max(1, g.lm_max_iterations) : 1);
-  const int max_rounds = per_pair_rounds * (n - window + 1) + 1 + 2 * (n - window);   // + the rounds a handed-over pair spends PENDING
+  // Up to 256 pairs with a window of at most 64: the window is kept by the HOST.  Only the pairs of the launch list run; when the
+  // status byte of a pair says "done" the next queued pair takes its place in the list (it was initialised with the others and
+  // simply never launched before).  Every round then carries about `window` live pairs, so the fixed cost of a round (two launches,
+  // their boundaries) is shared by that many registrations for the whole batch, not only in its first rounds.  No device-side hand-off.
+  const bool host_window = window < n && n <= 256 && window <= 64;
+  const int max_rounds = host_window ? per_pair_rounds * ((n + window - 1) / window + 1) + 4
+                                     : per_pair_rounds * (n - window + 1) + 1 + 2 * (n - window);   // + the rounds a handed-over pair spends PENDING
   const size_t per_pair_partials = (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride;
   Workspace* w = nullptr;
   int rc = ensure_ws(c0, &w, n, per_pair_partials * n, max_rounds);
@@ -511,7 +517,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   for (int i = 0; i < n; i++) fill_desc(ctxs[i], &descs[i], w->d_partials + per_pair_partials * i);
   HIPCK(c0, hipMemcpyAsync(w->d_descs, descs.data(), sizeof(PairDesc) * n, hipMemcpyHostToDevice, st));
   std::memset(w->h_flags, 0, (size_t)max_rounds * n);
-  launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations, window, w->d_queue);
+  launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations, host_window ? n : window, w->d_queue);
   const bool stats_on = (c0->profiling & 1) != 0;      // HIP events around the residual launches
   const bool timing_on = (c0->profiling & 4) != 0;     // diagnostic: in-kernel phase stamps (stats.phase_cycles)
   const bool counters_on = (c0->profiling & 2) != 0 || timing_on;   // kNN candidate / probe counters (slower kernel variant)
@@ -524,9 +530,10 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   // Only the pairs the host still believes active are launched (the list rides in the kernel arguments, batches of
   // <= 64 pairs): an early-exit workgroup is not free, and the late rounds of a batch have one or two live pairs.
   // The list lags one round (the status bytes are read one round behind); a stale entry exits at once.
-  const bool use_list = n <= 64 && window == n;
-  std::vector<uint8_t> act((size_t)n);
-  for (int i = 0; i < n; i++) act[(size_t)i] = (uint8_t)i;
+  const bool use_list = (n <= 64 && window == n) || host_window;
+  std::vector<uint8_t> act((size_t)(host_window ? window : n));
+  for (size_t i = 0; i < act.size(); i++) act[i] = (uint8_t)i;
+  int next_queued = host_window ? window : n;   // host window: first pair that has not been launched yet
   std::vector<uint8_t> prev_list;
   KernelParams kpr = kp;
   for (int r = 0; r < max_rounds; r++) {
@@ -581,6 +588,15 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
         }
         any_active |= row[i] == 1;
         if (row[i] == 1 && use_list) alive.push_back((uint8_t)i);
+      }
+      if (host_window) {
+        // pairs launched in round r (this_list) but not in round r - 1 have no status byte yet: they stay
+        for (uint8_t i : this_list) {
+          bool seen = false;
+          for (uint8_t q : prev_list) if (q == i) { seen = true; break; }
+          if (!seen) { alive.push_back(i); any_active = true; }
+        }
+        while ((int)alive.size() < window && next_queued < n) { alive.push_back((uint8_t)next_queued++); any_active = true; }
       }
       if (!any_active) break;
       if (use_list) act.swap(alive);

@@ -320,3 +320,25 @@ def test_batch_window_hand_off_with_more_pairs_than_resident_workgroups(pcm, syn
     for k in range(n):
         s, b = singles[k % len(base)], batch[k]
         assert np.array_equal(s.T64, b.T64) and s.iterations == b.iterations and s.num_linearize == b.num_linearize, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer", ["GN", "LM"])
+def test_host_window_equals_singles(pcm, synth, optimizer):
+    """batch_window with up to 256 pairs and a window <= 64 is kept by the host: only the launch list's pairs run and a finished
+    pair's place goes to the next queued one.  Every pair's result is the one it gets alone, whatever the window."""
+    base = [synth.make_pair(90 + i, 900 + 150 * i, 9000 + 1500 * i) for i in range(6)]
+    n = 40
+    for window in (1, 7, 16):
+        regs, guesses = [], []
+        for k in range(n):
+            p = base[k % len(base)]
+            g = pcm.P2PlaneRegistration(0, optimizer=optimizer, batch_window=window, max_iterations=20)
+            g.set_input_target(p.submap); g.set_input_source(p.scan)
+            regs.append(g); guesses.append(p.guess)
+        batch = pcm.align_batch(regs, np.stack(guesses))
+        singles = [regs[k].align(base[k].guess) for k in range(len(base))]
+        for k in range(n):
+            s, b = singles[k % len(base)], batch[k]
+            assert np.array_equal(s.T64, b.T64) and s.iterations == b.iterations and s.num_linearize == b.num_linearize, (window, k)
+            assert s.num_compute_error == b.num_compute_error and s.converged == b.converged
