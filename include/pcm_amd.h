@@ -231,6 +231,13 @@ int pcm_get_target(pcm_ctx *ctx, float *out_xyz, size_t capacity_points, size_t 
  * (pointcloud_match/ndt_omp/include/pclomp/ndt_omp_impl.hpp:168-267, 498-559). */
 int pcm_ndt_derivatives(pcm_ctx *ctx, const double p[6], int pass, double *score, double g[6], double H[36]);
 
+/* pcl::Registration::getFitnessScore(max_range) on the device: the source cloud transformed by the float pose T (row-major 4x4),
+ * exact nearest target point of every source point, mean of the squared distances that are <= max_range (PCL compares the SQUARED
+ * distance with max_range; its default is the largest double).  No point in range: the largest double, as PCL returns.
+ * Replaces the CPU kd-tree pass every call site runs right after align(): jueying_slam/src/localization.cpp:325-326,
+ * jueying_slam/src/mapOptmization.cpp:693,719, fast_gicp/src/align.cpp:63, fast_gicp/src/python/main.cpp get_fitness_score. */
+int pcm_fitness_score(pcm_ctx *ctx, const float T[16], double max_range, double *score);
+
 /* pclomp NDT: calculateScore (ndt_omp_impl.hpp:835-880) of the source cloud transformed by T (row-major float 4x4) */
 int pcm_ndt_score(pcm_ctx *ctx, const float T[16], double *score);
 

@@ -20,7 +20,9 @@
 #include <pcl/registration/registration.h>
 
 #include <Eigen/Core>
+#include <Eigen/Eigenvalues>
 #include <Eigen/Geometry>
+#include <cfloat>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -76,6 +78,18 @@ public:
   void setDebugPrint(bool) {}
   void setOptimizer(LSQ_OPTIMIZER_TYPE t) { cfg_.optimizer = t == LSQ_OPTIMIZER_TYPE::GaussNewton ? PCM_OPT_GAUSS_NEWTON : PCM_OPT_LEVENBERG_MARQUARDT; }
   const Eigen::Matrix<double, 6, 6>& getFinalHessian() const { return final_hessian_; }
+  int getFinalNumIteration() const { return nr_iterations_; }                                    // ndt_omp.h:228-232
+
+  // pcl::Registration::getFitnessScore(max_range) on the device (pcm_fitness_score): every reference call site asks for it right
+  // after align() (localization.cpp:325-326, mapOptmization.cpp:693,719, align.cpp:63).  PCL's member is NOT virtual: a call through
+  // a pcl::Registration base pointer still runs PCL's CPU kd-tree pass -- keep the adapter's type at the call site.
+  double getFitnessScore(double max_range = DBL_MAX) {
+    float T[16];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T[i * 4 + j] = final_transformation_(i, j);
+    double score = 0.0;
+    check(pcm_fitness_score(ctx_, T, max_range, &score), "pcm_fitness_score");
+    return score;
+  }
 
   double evaluateCost(const Eigen::Matrix4f& relative_pose, Eigen::Matrix<double, 6, 6>* H = nullptr, Eigen::Matrix<double, 6, 1>* b = nullptr) {
     push_config();
@@ -89,7 +103,10 @@ public:
 
   // ---- FastGICP surface (fast_gicp_impl.hpp:26-90) ----
   void setNumThreads(int) {}                                             // no meaning on the GPU
-  void setMaxCorrespondenceDistance(double d) { cfg_.max_range = static_cast<float>(d); cfg_.max_corr_dist = static_cast<float>(d); }
+  // corr_dist_threshold_ of the GICP family (fast_gicp_impl.hpp:18,136).  The point-to-plane matcher does not read it: its
+  // search radius is iVox's own max_range (ivox3d.h:132, 5.0 m), which stays what the configuration says.
+  void setMaxCorrespondenceDistance(double d) { Base::setMaxCorrespondenceDistance(d); cfg_.max_corr_dist = static_cast<float>(d); }
+  void setMaxRange(double r) { cfg_.max_range = static_cast<float>(r); }   // IVox::GetClosestPoint max_range
   void setResolution(double r) { cfg_.voxel_resolution = static_cast<float>(r); }      // fast_vgicp_impl.hpp:28-30
   void setNumNeighborCells(int n) { cfg_.num_neighbors = n; }            // ivox_nearby_type 0/6/18/26 -> 1/7/19/27
 
@@ -154,6 +171,7 @@ public:
 // fast_gicp::FastGICP (gicp/fast_gicp.hpp:24-95): setCorrespondenceRandomness, setRegularizationMethod, covariances
 enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };   // gicp_settings.hpp
 enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1 };                               // gicp_settings.hpp
+enum class VoxelAccumulationMode { ADDITIVE, ADDITIVE_WEIGHTED, MULTIPLICATIVE };              // gicp_settings.hpp
 
 template <typename PointSource, typename PointTarget>
 class GicpRegistration : public LsqRegistration<PointSource, PointTarget> {
@@ -189,6 +207,7 @@ public:
     this->cfg_.num_neighbors = 1;
   }
   void setNeighborSearchMethod(NeighborSearchMethod m) { this->cfg_.num_neighbors = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1); }
+  void setVoxelAccumulationMode(VoxelAccumulationMode m) { this->cfg_.voxel_mode = static_cast<int>(m); }   // fast_vgicp_impl.hpp:38-40
 };
 
 // fast_gicp::NDTCuda (ndt/ndt_cuda.hpp:21-71): D2D, DIRECT7, resolution 1.0  (cuda/ndt_cuda.cu:15-22)
@@ -224,6 +243,24 @@ public:
     this->cfg_.num_neighbors = m == KDTREE ? 0 : (m == DIRECT26 ? 27 : (m == DIRECT7 ? 7 : 1));
   }
   double getTransformationProbability() const { return trans_probability_; }                     // ndt_omp.h:207
+  // getMaxEigen (ndt_omp.h:209-223): largest pseudo-eigenvalue of the final Hessian / 1e5 -- the degeneracy metric of the localisation node
+  double getMaxEigen() const {
+    Eigen::EigenSolver<Eigen::Matrix<double, 6, 6>> eigen_solver(this->final_hessian_);
+    const Eigen::Matrix<double, 6, 6> mat_E = eigen_solver.pseudoEigenvalueMatrix();
+    double max_eigen = mat_E(0, 0);
+    for (int i = 0; i < 6; i++) if (mat_E(i, i) > max_eigen) max_eigen = mat_E(i, i);
+    return max_eigen / 100000.0;
+  }
+  // calculateScore(cloud) (ndt_omp_impl.hpp:835-880): negative log likelihood of the ALREADY TRANSFORMED cloud the caller passes;
+  // here the source cloud under the given pose (identity = the cloud as it is)
+  double calculateScore(const Eigen::Matrix4f& pose = Eigen::Matrix4f::Identity()) {
+    this->push_config();
+    float T[16];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T[i * 4 + j] = pose(i, j);
+    double score = 0.0;
+    this->check(pcm_ndt_score(this->ctx_, T, &score), "pcm_ndt_score");
+    return score;
+  }
 protected:
   void computeTransformation(typename LsqRegistration<PointSource, PointTarget>::PointCloudSource& output,
                              const typename LsqRegistration<PointSource, PointTarget>::Matrix4& guess) override {
@@ -234,5 +271,20 @@ protected:
 };
 
 }  // namespace pcm_amd
+
+// The call sites spell the pclomp enumerators unqualified inside namespace pclomp (jueying_slam/src/localization.cpp:169-186:
+// `ndt->setNeighborhoodSearchMethod(pclomp::DIRECT7)`).  Define PCM_AMD_PCLOMP_ALIASES before including this header, in a
+// translation unit that no longer includes <pclomp/ndt_omp.h>, to keep those lines unchanged.
+#ifdef PCM_AMD_PCLOMP_ALIASES
+namespace pclomp {
+using NeighborSearchMethod = pcm_amd::NeighborSearchMethodOmp;
+using pcm_amd::KDTREE;
+using pcm_amd::DIRECT26;
+using pcm_amd::DIRECT7;
+using pcm_amd::DIRECT1;
+template <typename PointSource, typename PointTarget>
+using NormalDistributionsTransform = pcm_amd::PclNdtRegistration<PointSource, PointTarget>;
+}  // namespace pclomp
+#endif
 
 #endif  // __has_include(<pcl/registration/registration.h>)

@@ -87,6 +87,8 @@ def lib():
         L.orc_pclndt_pose.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_pclndt_euler.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_pclndt_svd_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_fitness_score.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+        L.orc_fitness_score.restype = C.c_double
         L.orc_test_knn_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_test_covariances.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_test_covariances_f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -204,6 +206,11 @@ class Oracle:
         mean = np.zeros(3); icov = np.zeros((3, 3)); n = C.c_int(0)
         ok = lib().orc_pclndt_leaf(self._h, pt.ctypes.data, mean.ctypes.data, icov.ctypes.data, C.byref(n))
         return (mean, icov, n.value) if ok else None
+
+    def fitness_score(self, T, max_range=float(np.finfo(np.float64).max)):
+        """pcl::Registration::getFitnessScore(max_range) under the float pose T."""
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        return lib().orc_fitness_score(self._h, T.ctypes.data, float(max_range))
 
     def knn_exact(self, q, k):
         q = np.ascontiguousarray(q, dtype=np.float32)

@@ -471,3 +471,30 @@ void orc_test_covariances(void *h, int target, double *covs) {
   oracle *o = (oracle *)h;
   orc_calc_covariances(o, target ? &o->tgt : &o->src, covs);
 }
+
+/* ---- pcl::Registration::getFitnessScore(max_range)  (PCL is not in the reference tree; restated from pcl/registration/impl/
+ * registration.hpp as the call sites use it: jueying_slam/src/localization.cpp:325-326, mapOptmization.cpp:693,719,
+ * fast_gicp/src/align.cpp:63).  The input cloud is transformed by final_transformation_ in float (pcl::transformPointCloud),
+ * every point looks up its exact nearest target point (kd-tree 1-NN), and the SQUARED distance is compared with max_range
+ * itself (PCL's own quirk) and averaged over the points that pass; no point passes -> numeric_limits<double>::max(). ---- */
+double orc_fitness_score(void *h, const float T[16], double max_range) {
+  oracle *o = (oracle *)h;
+  if (o->src.n <= 0 || o->tgt.n <= 0) return DBL_MAX;
+  orc_grid g;
+  memset(&g, 0, sizeof(g));
+  grid_build(&g, &o->tgt, o->cfg.voxel_resolution > 0 ? o->cfg.voxel_resolution : 1.0);
+  double sum = 0.0;
+  long nr = 0;
+#pragma omp parallel for reduction(+ : sum, nr) schedule(dynamic, 256)
+  for (long i = 0; i < o->src.n; i++) {
+    const float *p = o->src.xyz + 3 * i;
+    float q[3];
+    for (int a = 0; a < 3; a++) q[a] = T[a * 4 + 0] * p[0] + (T[a * 4 + 1] * p[1] + (T[a * 4 + 2] * p[2] + T[a * 4 + 3]));
+    int idx[1];
+    float d2[1];
+    if (grid_knn(&g, &o->tgt, q, 1, 1e300, idx, d2) < 1) continue;
+    if ((double)d2[0] <= max_range) { sum += (double)d2[0]; nr++; }
+  }
+  grid_free(&g);
+  return nr > 0 ? sum / (double)nr : DBL_MAX;
+}

@@ -20,6 +20,9 @@
 
 #ifdef __cplusplus
 extern "C" {
+/* pcl::Registration::getFitnessScore(max_range) of the source cloud under T (orc_gicp.c) */
+double orc_fitness_score(void *h, const float T[16], double max_range);
+
 #endif
 
 enum { ORC_MODEL_P2PLANE = 0, ORC_MODEL_GICP = 1, ORC_MODEL_VGICP = 2, ORC_MODEL_NDT_P2D = 3, ORC_MODEL_NDT_D2D = 4, ORC_MODEL_NDT_OMP = 5, ORC_MODEL_VGICP_CUDA = 6 };

@@ -833,4 +833,48 @@ void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_fitness: pcl::Registration::getFitnessScore(max_range) on the device.  Every reference call site asks for it right
+// after align() (jueying_slam/src/localization.cpp:325-326, mapOptmization.cpp:693,719, fast_gicp/src/align.cpp:63); PCL
+// answers with a CPU kd-tree 1-NN of every source point in the target -- tens of milliseconds against a 130 us registration.
+// Here: the source point transformed by the FLOAT final transformation (pcl::transformPointCloud), its exact nearest map point
+// by the voxel-column box walk of the GICP correspondence search (nearest1), the squared distance compared with max_range
+// itself (PCL's own quirk: pcl/registration/impl/registration.hpp getFitnessScore), sum and count in double.
+// grid = ceil(n / 256), block = 256; one (sum, count) row per block, added by the host in block order.
+// ---------------------------------------------------------------------------
+struct FitnessPose { float m[12]; };
+
+__global__ void __launch_bounds__(256) k_fitness(TargetView tg, int coord_mode, const float4* __restrict__ src, uint32_t n, FitnessPose P, double max_range, double* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  double d2sum = 0.0, cnt = 0.0;
+  if (i < n) {
+    const float4 p = gload4(src + i);
+    float q[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) q[a] = P.m[a * 4 + 0] * p.x + (P.m[a * 4 + 1] * p.y + (P.m[a * 4 + 2] * p.z + P.m[a * 4 + 3]));
+    const int j = nearest1(tg, coord_mode, q, 1.0e300);
+    if (j >= 0) {
+      const float4 mp = gload4(tg.pts + j);
+      const float dx = mp.x - q[0], dy = mp.y - q[1], dz = mp.z - q[2];
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      if ((double)d2 <= max_range) { d2sum = (double)d2; cnt = 1.0; }
+    }
+  }
+  __shared__ double s_sum[4], s_cnt[4];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { d2sum += __shfl_xor(d2sum, off, 64); cnt += __shfl_xor(cnt, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = d2sum; s_cnt[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x + 0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+    out[2 * blockIdx.x + 1] = ((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3];
+  }
+}
+
+void launch_fitness(hipStream_t stream, const TargetView& tg, int coord_mode, const float4* src, uint32_t n, const float* T, double max_range, double* d_out) {
+  FitnessPose P;
+  for (int a = 0; a < 12; a++) P.m[a] = T[a];
+  k_fitness<<<(n + 255u) / 256u, 256, 0, stream>>>(tg, coord_mode, src, n, P, max_range, d_out);
+}
+
 }  // namespace pcm

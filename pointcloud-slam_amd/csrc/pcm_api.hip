@@ -912,6 +912,35 @@ int pcm_ndt_score(pcm_ctx* c, const float T[16], double* score) {
   return PCM_OK;
 }
 
+// pcl::Registration::getFitnessScore(max_range): mean squared distance of the source points, transformed by T, to their exact
+// nearest target points, over the points whose squared distance is <= max_range (call sites: localization.cpp:325-326,
+// mapOptmization.cpp:693,719, fast_gicp/src/align.cpp:63)
+int pcm_fitness_score(pcm_ctx* c, const float T[16], double max_range, double* score) {
+  CHECK_CTX(c);
+  if (!T || !score) return PCM_ERR_INVALID_ARGUMENT;
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  rc = prepare(c);
+  if (rc != PCM_OK) return rc;
+  if (!c->map.valid || !c->map.pts || c->src.n == 0) { c->err = "pcm_fitness_score: set a source and a target first"; return PCM_ERR_INVALID_ARGUMENT; }
+  PairDesc d;
+  fill_desc(c, &d, nullptr);
+  const uint32_t n = (uint32_t)c->src.n;
+  const uint32_t nblocks = (n + 255u) / 256u;
+  Workspace* w = nullptr;
+  rc = ensure_ws(c, &w, 1, (size_t)std::max<uint32_t>(2u * nblocks, kPartialStride), 2);
+  if (rc != PCM_OK) return rc;
+  launch_fitness(c->stream, d.tgt, coord_mode_for(c->cfg.model), c->src.d_pts, n, T, max_range, w->d_partials);
+  HIPCK(c, hipGetLastError());
+  std::vector<double> rows(2 * (size_t)nblocks);
+  HIPCK(c, hipMemcpyAsync(rows.data(), w->d_partials, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  double sum = 0.0, cnt = 0.0;
+  for (uint32_t b = 0; b < nblocks; b++) { sum += rows[2 * b]; cnt += rows[2 * b + 1]; }
+  *score = cnt > 0.0 ? sum / cnt : DBL_MAX;
+  return PCM_OK;
+}
+
 // ImuProcess::UndistortPcl backward propagation  (jueying_lio/include/imu_processing.hpp:245-285)
 int pcm_undistort(pcm_ctx* c, void* points, size_t n, size_t stride, size_t time_off, int memory, const pcm_imu_pose* poses, int npose, const pcm_lio_state* st) {
   CHECK_CTX(c);

@@ -104,6 +104,7 @@ void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* 
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
                          bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue = nullptr, int total_pairs = 0);
 void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, int kind, bool trial);   // kind 0 P2D, 1 D2D, 2 VGICP_CUDA
+void launch_fitness(hipStream_t stream, const TargetView& tg, int coord_mode, const float4* src, uint32_t n, const float* T, double max_range, double* d_out);
 void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
 int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err);

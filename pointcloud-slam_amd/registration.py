@@ -264,6 +264,16 @@ class Registration:
         self._check(self._L.pcm_get_planes(self._h, out.ctypes.data, n))
         return out
 
+    def get_fitness_score(self, max_range: float = float(np.finfo(np.float64).max), T=None) -> float:
+        """pcl::Registration::getFitnessScore(max_range) (pygicp get_fitness_score, main.cpp:169-215): mean squared distance of
+        the source points under the final transformation (or T) to their exact nearest target points, on the device."""
+        if T is None:
+            T = self._last.T
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        s = C.c_double()
+        self._check(self._L.pcm_fitness_score(self._h, T.ctypes.data, float(max_range), C.byref(s)))
+        return s.value
+
     def get_final_transformation(self): return self._last.T
     def get_final_hessian(self): return self._last.H
     def has_converged(self): return self._last.converged

@@ -77,3 +77,27 @@ def test_preprocess_arena_survives_a_registration_on_the_same_context(pcm):
         again = g.voxel_downsample(scan, 0.5)
         assert np.array_equal(first, again)
         del g                                                  # every buffer released exactly once
+
+
+@pytest.mark.parametrize("model", ["P2PLANE", "GICP", "NDT_OMP"])
+def test_fitness_score_matches_oracle(pcm, synth, model):
+    """pcm_fitness_score = pcl::Registration::getFitnessScore(max_range) on the device: exact 1-NN of every transformed source
+    point, squared distances <= max_range averaged (PCL compares the squared distance with max_range), the largest double when
+    nothing is in range.  Against the oracle's brute-force-checked kd-tree stand-in, for the models the call sites use."""
+    from oracle import Oracle
+    p = synth.make_pair(3, 6000, 60000)
+    cls = {"P2PLANE": pcm.P2PlaneRegistration, "GICP": pcm.GicpRegistration, "NDT_OMP": pcm.PclNdtRegistration}[model]
+    g = cls(0)
+    g.set_input_target(p.submap); g.set_input_source(p.scan)
+    o = Oracle("P2PLANE", "GN", voxel_resolution=0.5)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    for T in (p.guess, p.T_gt.astype(np.float32)):
+        for max_range in (np.finfo(np.float64).max, 0.04, 1e-12):
+            s_gpu = g.get_fitness_score(max_range, T)
+            s_ref = o.fitness_score(T, max_range)
+            if s_ref == np.finfo(np.float64).max:
+                assert s_gpu == s_ref
+            else:
+                assert abs(s_gpu - s_ref) <= 1e-12 * s_ref, (model, max_range, s_gpu, s_ref)
+    r = g.align(p.guess)
+    assert g.get_fitness_score() == g.get_fitness_score(T=r.T)     # default: the final transformation of the last align
