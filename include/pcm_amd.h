@@ -95,7 +95,7 @@ typedef struct pcm_config {
   int32_t k_correspondences;     /* 20  impl/fast_gicp_impl.hpp:16 */
   int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
   int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
-  int32_t flags;                 /* PCM_FLAG_* (speed / debugging only, never changes a result) */
+  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics */
   int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
   float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
@@ -105,6 +105,12 @@ typedef struct pcm_config {
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
+#define PCM_FLAG_LIO_REFERENCE_SEMANTICS 4
+/* pcm_obs_model keeps residuals_ and point_selected_surf_ across calls AND scans exactly as the members of LaserMapping do
+ * (jueying_lio/src/laser_mapping.cc:335-339 one resize-with-default per frame; :616-636 a selected point that fails the
+ * `p_body.norm() > 81 pd2^2` test keeps its flag and contributes the residual an earlier call -- possibly of an older frame --
+ * stored for its index; a point never stored contributes 0).  Set it before pcm_set_source of the first scan.  Off (default):
+ * such a point is dropped for that call, the result depends on the current scan, map and state only. */
 #define PCM_FLAG_FUSED_STEP 2       /* GN: take the step in the search kernel's last workgroup (write-through hand-off of the partial rows) instead of
                                      * a second launch; same sums in the same order; measured slower at every round size, off by default */
 
@@ -183,6 +189,11 @@ int pcm_compute_error(pcm_ctx *ctx, const double T[16], double *cost);
  * scan's device order; nx = NaN marks a point that was not selected.  `out`
  * holds 4*n floats. */
 int pcm_get_planes(pcm_ctx *ctx, float *out, size_t n);
+
+/* parity hook for PCM_FLAG_LIO_REFERENCE_SEMANTICS: residuals_[i] and point_selected_surf_[i]
+ * (jueying_lio/src/laser_mapping.cc:337-338, 619-635) as the last pcm_obs_model left them, in the order of the
+ * caller's scan; n must equal the source size. */
+int pcm_get_lio_members(pcm_ctx *ctx, float *residuals, uint8_t *selected, size_t n);
 
 /* jueying_lio measurement model: the h_dyn_share callback LaserMapping::ObsModel
  * (jueying_lio/src/laser_mapping.cc:592-701) together with the reduction the IEKF applies

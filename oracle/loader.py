@@ -62,6 +62,9 @@ def lib():
         L.orc_num_inliers.argtypes = [C.c_void_p]
         L.orc_get_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
         L.orc_obs_model.argtypes = [C.c_void_p, C.POINTER(LioState), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.orc_set_lio_reference_semantics.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_lio_reference_semantics.restype = None
+        L.orc_get_lio_members.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
         L.orc_target_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long]
         L.orc_map_incremental.argtypes = [C.c_void_p, C.POINTER(LioState), C.c_double, C.c_int, C.POINTER(C.c_long)]
         L.orc_target_size.restype = C.c_long
@@ -165,6 +168,16 @@ class Oracle:
         HTH = np.zeros((12, 12)); HTh = np.zeros(12); n = C.c_int(); s2 = C.c_double()
         lib().orc_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), HTH.ctypes.data, HTh.ctypes.data, C.byref(n), C.byref(s2))
         return HTH, HTh, n.value, s2.value
+
+    def set_lio_reference_semantics(self, on=True):
+        """Keep residuals_/point_selected_surf_/plane_coef_ across calls and frames as LaserMapping's members do."""
+        lib().orc_set_lio_reference_semantics(self._h, int(bool(on)))
+
+    def get_lio_members(self, n):
+        pl = np.zeros((n, 4), np.float32); res = np.zeros(n, np.float32); sel = np.zeros(n, np.uint8)
+        if lib().orc_get_lio_members(self._h, pl.ctypes.data, res.ctypes.data, sel.ctypes.data, n) != 0:
+            raise RuntimeError("orc_get_lio_members")
+        return pl, res, sel.astype(bool)
 
     def target_insert(self, pts):
         a = _f32(pts)

@@ -47,6 +47,13 @@ typedef struct oracle {
   struct orc_lru_state *lru;   /* sliding-map state (orc_lru.c) */
   int *nn;                     /* [n_src][5] target indices of the last matching call, -1 = none */
   long nn_cap;
+  /* LaserMapping members that outlive one ObsModel call and one frame (laser_mapping.cc:335-339): kept only
+   * in the reference-semantics mode of orc_obs_model */
+  int lio_ref;                 /* orc_set_lio_reference_semantics */
+  float *ref_plane;            /* plane_coef_           [ref_n][4] */
+  float *ref_resid;            /* residuals_            [ref_n]    */
+  unsigned char *ref_sel;      /* point_selected_surf_  [ref_n]    */
+  long ref_n, ref_cap;
 } oracle;
 
 void orc_vhash_init(orc_vhash *h, long expected);

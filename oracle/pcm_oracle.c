@@ -438,9 +438,44 @@ static void quat_to_rot_xyzw(const double q[4], double R[9]) {
   orc_quat_to_rot(w, R);
 }
 
+/* residuals_.resize(cur_pts, 0); point_selected_surf_.resize(cur_pts, true); plane_coef_.resize(cur_pts, V4F::Zero())
+ * laser_mapping.cc:337-339 -- std::vector::resize: the first min(old, new) entries survive, appended ones take the default */
+static void lio_ref_resize(oracle *o, long n) {
+  if (n > o->ref_cap) {
+    long cap = n + n / 2 + 16;
+    o->ref_plane = (float *)realloc(o->ref_plane, sizeof(float) * 4 * (size_t)cap);
+    o->ref_resid = (float *)realloc(o->ref_resid, sizeof(float) * (size_t)cap);
+    o->ref_sel = (unsigned char *)realloc(o->ref_sel, (size_t)cap);
+    o->ref_cap = cap;
+  }
+  for (long i = o->ref_n; i < n; i++) {
+    o->ref_plane[4 * i] = o->ref_plane[4 * i + 1] = o->ref_plane[4 * i + 2] = o->ref_plane[4 * i + 3] = 0.f;
+    o->ref_resid[i] = 0.f;
+    o->ref_sel[i] = 1;
+  }
+  o->ref_n = n;
+}
+
+void orc_set_lio_reference_semantics(void *h, int on) {
+  oracle *o = (oracle *)h;
+  o->lio_ref = on != 0;
+  if (on) lio_ref_resize(o, o->src.n);
+}
+
+int orc_get_lio_members(void *h, float *plane4, float *resid, unsigned char *selected, long n) {
+  oracle *o = (oracle *)h;
+  if (!o->lio_ref || n != o->ref_n) return -1;
+  memcpy(plane4, o->ref_plane, sizeof(float) * 4 * (size_t)n);
+  memcpy(resid, o->ref_resid, sizeof(float) * (size_t)n);
+  memcpy(selected, o->ref_sel, (size_t)n);
+  return 0;
+}
+
 int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int converge, double HTH[144], double HTh[12], int *n_eff, double *sum_h2) {
   oracle *o = (oracle *)h;
   p2plane_prepare(o);
+  const int ref = o->lio_ref;
+  if (ref) lio_ref_resize(o, o->src.n);
   /* R_wl = (s.rot * s.offset_R_L_I).cast<float>() ; t_wl = (s.rot * s.offset_T_L_I + s.pos).cast<float>()   :602-603 */
   double qwl[4], twl[3];
   quat_mul(s->rot, s->off_R, qwl);
@@ -469,7 +504,8 @@ int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int con
     float q[3];
     quat_rot_f(qf, p, q);
     for (int a = 0; a < 3; a++) q[a] = q[a] + tf[a];
-    float *pl = o->plane + 4 * i;
+    float *pl = ref ? o->ref_plane + 4 * i : o->plane + 4 * i;
+    unsigned char *selp = ref ? o->ref_sel + i : o->selected + i;
     int sel;
     if (converge) {
       int m = orc_ivox_knn(o, q, idx, NULL, &buf);
@@ -479,14 +515,20 @@ int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int con
         for (int j = 0; j < m; j++) for (int a = 0; a < 3; a++) near[j * 3 + a] = o->tgt.xyz[3 * (long)idx[j] + a];
         sel = orc_esti_plane(near, m, K, o->cfg.min_knn, (float)o->cfg.plane_threshold, pl);
       }
-      o->selected[i] = (unsigned char)sel;   /* plane validity only; the residual test below is re-evaluated every call */
+      *selp = (unsigned char)sel;   /* plane validity only; the residual test below is re-evaluated every call */
     } else {
-      sel = o->selected[i];
+      sel = *selp;
     }
     if (!sel) continue;
-    const float pd2 = pl[0] * q[0] + pl[1] * q[1] + pl[2] * q[2] + pl[3];
+    float pd2 = pl[0] * q[0] + pl[1] * q[1] + pl[2] * q[2] + pl[3];
     const float pn = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-    if (!(pn > 81.f * pd2 * pd2)) continue;   /* clean semantics: dropped for this call */
+    if (ref) {
+      /* :631-635  the flag stays true either way; a failing point keeps the residual an earlier call stored at index i */
+      if (pn > 81.f * pd2 * pd2) o->ref_resid[i] = pd2;
+      pd2 = o->ref_resid[i];   /* corr_pts_[.][3] = residuals_[i]  :649 */
+    } else if (!(pn > 81.f * pd2 * pd2)) {
+      continue;   /* clean semantics: dropped for this call */
+    }
     /* Jacobian row   :674-698 */
     float pthis[3];
     for (int a = 0; a < 3; a++) pthis[a] = (offR[a * 3 + 0] * p[0] + offR[a * 3 + 1] * p[1]) + offR[a * 3 + 2] * p[2] + offt[a];
@@ -677,6 +719,9 @@ void orc_destroy(void *h) {
   ivox_free(&o->tgt_ivox);
   free(o->plane);
   free(o->selected);
+  free(o->ref_plane);
+  free(o->ref_resid);
+  free(o->ref_sel);
   free(o->nn);
   orc_lru_free(o);
   orc_gauss_free(o);
@@ -699,6 +744,7 @@ int orc_set_target(void *h, const float *xyz, long n, long stride) {
 int orc_set_source(void *h, const float *xyz, long n, long stride) {
   oracle *o = (oracle *)h;
   cloud_set(&o->src, xyz, n, stride);
+  if (o->lio_ref) lio_ref_resize(o, n);   /* one resize per frame  laser_mapping.cc:335-339 */
   orc_gauss_invalidate(o, 0);
   orc_gicp_invalidate(o, 0);
   return 0;

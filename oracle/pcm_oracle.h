@@ -108,6 +108,13 @@ int orc_gicp_bfgs_fdf(const float *src, const float *tgt, long stride_f, const i
  * (5-NN + plane fit); converge == 0: re-use the planes of the previous call.  Returns 0, or -1
  * when there is no effective point (ekfom_data.valid = false, :657-661). */
 int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int converge, double HTH[144], double HTh[12], int *n_eff, double *sum_h2);
+/* on != 0: orc_obs_model keeps residuals_, point_selected_surf_ and plane_coef_ across calls AND frames exactly as the
+ * members of LaserMapping do (laser_mapping.cc:335-339 resize-with-default per frame; :616-636 a selected point that
+ * fails the 81 pd2^2 test stays selected and contributes the residual stored for its index by an earlier call).
+ * on == 0 (default): the clean semantics of SURVEY a14 -- such a point is dropped for that call. */
+void orc_set_lio_reference_semantics(void *h, int on);
+/* the three per-point members after the last orc_obs_model in reference-semantics mode (n = current scan size) */
+int orc_get_lio_members(void *h, float *plane4, float *resid, unsigned char *selected, long n);
 
 /* IVox::AddPoints with the LRU voxel cache (jueying_lio/include/ivox3d/ivox3d.h:256-281) */
 int orc_target_insert(void *h, const float *xyz, long n, long stride_floats);

@@ -13,11 +13,14 @@ SYMBOLS = [
     "pcm_abi_version", "pcm_default_config", "pcm_create", "pcm_destroy", "pcm_last_error",
     "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
     "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
-    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_ndt_derivatives", "pcm_ndt_score", "pcm_fitness_score", "pcm_undistort", "pcm_voxel_downsample", "pcm_gicp_bfgs_set_correspondences", "pcm_gicp_bfgs_fdf", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
+    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_get_lio_members", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_ndt_derivatives", "pcm_ndt_score", "pcm_fitness_score", "pcm_undistort", "pcm_voxel_downsample", "pcm_gicp_bfgs_set_correspondences", "pcm_gicp_bfgs_fdf", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
 PCM_OK = 0
+PCM_FLAG_NO_LDS_STAGING = 1
+PCM_FLAG_FUSED_STEP = 2
+PCM_FLAG_LIO_REFERENCE_SEMANTICS = 4   # pcm_obs_model keeps LaserMapping's per-point members across calls and scans
 PCM_ERR_NOT_CONVERGED = -6
 MEM_HOST, MEM_DEVICE = 0, 1
 MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5, "VGICP_CUDA": 6}
@@ -119,6 +122,7 @@ def load_library():
     L.pcm_linearize.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.pcm_compute_error.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.pcm_get_planes.argtypes = [vp, vp, sz]
+    L.pcm_get_lio_members.argtypes = [vp, vp, vp, sz]
     L.pcm_obs_model.argtypes = [vp, C.POINTER(PcmLioState), i32, i32, C.POINTER(PcmObsResult)]
     L.pcm_target_insert.argtypes = [vp, vp, sz, sz, i32]
     L.pcm_map_incremental.argtypes = [vp, C.POINTER(PcmLioState), C.c_float, i32, C.POINTER(sz)]

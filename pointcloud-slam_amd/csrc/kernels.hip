@@ -422,6 +422,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 pl = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
   bool use_lds = false;
+  bool ref_fit = false, ref_ok = false;   // LIO reference semantics: esti_plane ran for this point (pl = what it wrote) / what it returned
   if (do_search) {
     // ---- voxel bounding box of the tile ---------------------------------------------------------
     {
@@ -624,7 +625,9 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
           px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
         }
         float4 fit;
-        if (esti_plane(px, py, pz, K, kp.plane_threshold, &fit)) pl = fit;
+        const bool ok = esti_plane(px, py, pz, K, kp.plane_threshold, &fit);
+        if (LIO && kp.lio_ref) { pl = fit; ref_fit = true; ref_ok = ok; }   // plane_coef_[i] is written whatever the verdict (common_lib.h:229-233)
+        else if (ok) pl = fit;
       } else if (best.m >= KMIN) {
         my_job = atomicAdd(&s_njobs, 1u);
         s_job[my_job] = threadIdx.x | ((uint32_t)best.m << 16);
@@ -645,14 +648,19 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
         px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
       }
       float4 fit;
-      if (!esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit)) fit.x = __builtin_nanf("");
+      const bool ok = esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit);
+      if (LIO && kp.lio_ref) s_job[job] = ok ? 1u : 0u;
+      else if (!ok) fit.x = __builtin_nanf("");
       s_jobid[job][0] = __float_as_uint(fit.x); s_jobid[job][1] = __float_as_uint(fit.y);   // hand the plane back to its owner lane
       s_jobid[job][2] = __float_as_uint(fit.z); s_jobid[job][3] = __float_as_uint(fit.w);
     }
     __syncthreads();   // also: nobody reads s_pts after this point (its memory is re-used below)
-    if (my_job != ~0u) pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
+    if (my_job != ~0u) {
+      pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
+      if (LIO && kp.lio_ref) { ref_fit = true; ref_ok = s_job[my_job] != 0u; }
+    }
   } else {
-    if (live) pl = gload4(d.planes + i);   // plane of the previous ObsModel call (NaN: none)
+    if (live) pl = gload4(d.planes + ((LIO && kp.lio_ref == 2) ? __float_as_uint(p.w) : i));   // plane of the previous ObsModel call (clean semantics: NaN = none)
     __syncthreads();
   }
 
@@ -666,12 +674,38 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
 #pragma unroll
       for (int a = 0; a < 16; a++) row[a] = 0.f;
       if (live) {
-        bool sel = !(pl.x != pl.x);
-        if (do_search) gstore4(d.planes + i, pl);                        // plane_coef_[i]; the residual test is re-evaluated every call
-        if (sel) {
-          const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
-          const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
-          sel = pn > 81.f * pd2 * pd2;
+        bool sel;
+        float res = 0.f;
+        if (kp.lio_ref) {
+          // the members of LaserMapping as they are: the flag and the plane of a point change only when a matching call
+          // reaches them, and a selected point that fails the 81 pd2^2 test keeps its flag and the residual stored for its
+          // index by an earlier call -- of this frame or of an older one (laser_mapping.cc:335-339, 616-636, 646-650)
+          const uint32_t oi = kp.lio_ref == 2 ? __float_as_uint(p.w) : i;
+          PCM_GLOBAL float* aux = (PCM_GLOBAL float*)d.lio_aux + 2 * (size_t)oi;
+          res = aux[0];
+          sel = aux[1] != 0.f;
+          if (do_search) {
+            sel = ref_fit && ref_ok;
+            if (ref_fit) gstore4(d.planes + oi, pl);
+          }
+          if (sel) {
+            const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
+            const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+            if (pn > 81.f * pd2 * pd2) res = pd2;
+          }
+          aux[0] = res;
+          aux[1] = sel ? 1.f : 0.f;
+        } else {
+          sel = !(pl.x != pl.x);
+          if (do_search) gstore4(d.planes + i, pl);                        // plane_coef_[i]; the residual test is re-evaluated every call
+          if (sel) {
+            res = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
+            const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+            sel = pn > 81.f * res * res;
+          }
+        }
+        {
+          const float pd2 = res;
           if (sel) {
             const float* oR = d.lio.off_R;
             const float* Rt = d.lio.Rt;
@@ -872,6 +906,15 @@ __global__ void __launch_bounds__(1024) k_lio_finish(const double* __restrict__ 
 
 void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out) {
   k_lio_finish<<<1, 1024, 0, stream>>>(d_partials, nblocks, d_out);
+}
+
+// residuals_.resize(n, 0); point_selected_surf_.resize(n, true): the appended entries  (laser_mapping.cc:337-338)
+__global__ void k_lio_members_init(float2* __restrict__ aux, uint32_t first, uint32_t last) {
+  const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < last) aux[i] = make_float2(0.f, 1.f);
+}
+void launch_lio_members_init(hipStream_t stream, float2* aux, uint32_t first, uint32_t last) {
+  if (last > first) k_lio_members_init<<<(last - first + 255u) / 256u, 256, 0, stream>>>(aux, first, last);
 }
 
 // ---------------------------------------------------------------------------

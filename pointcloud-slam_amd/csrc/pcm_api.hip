@@ -796,6 +796,7 @@ void pcm_destroy(pcm_ctx* c) {
     c->src.release();
     c->tgt.release();
     if (c->src_order) hipFree(c->src_order);
+    if (c->lio_aux) hipFree(c->lio_aux);
     c->map.release();
     c->srcmap.release();
     if (c->corr) hipFree(c->corr);
@@ -861,6 +862,27 @@ int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   return rc;
 }
 
+namespace {
+// residuals_.resize(cur_pts, 0); point_selected_surf_.resize(cur_pts, true)  (laser_mapping.cc:337-338): the first
+// min(old, new) entries survive a new scan, appended ones take the default.  plane_coef_ (:339) needs no such care: the
+// IEKF's first ObsModel call of a frame always matches (esekfom.hpp:1529) and rewrites every plane it may read later.
+static int lio_members_resize(pcm_ctx* c, size_t n) {
+  if (n > c->lio_aux_cap) {
+    const size_t cap = n + n / 2 + 1024;
+    float2* nb = nullptr;
+    HIPCK(c, hipMalloc(&nb, sizeof(float2) * cap));
+    if (c->lio_aux_n) HIPCK(c, hipMemcpyAsync(nb, c->lio_aux, sizeof(float2) * c->lio_aux_n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->lio_aux) hipFree(c->lio_aux);
+    c->lio_aux = nb;
+    c->lio_aux_cap = cap;
+  }
+  if (n > c->lio_aux_n) launch_lio_members_init(c->stream, c->lio_aux, (uint32_t)c->lio_aux_n, (uint32_t)n);
+  c->lio_aux_n = n;
+  return PCM_OK;
+}
+}  // namespace
+
 int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes, int memory, uint64_t tag) {
   CHECK_CTX(c);
   if (tag != 0 && tag == c->src.tag && c->src.n == n) return PCM_OK;  // fast_gicp_impl.hpp:72-74
@@ -868,6 +890,7 @@ int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   c->src_sorted = false;
   c->lio_planes_valid = false;
   c->srcmap.valid = false;
+  if (rc == PCM_OK && (c->cfg.flags & PCM_FLAG_LIO_REFERENCE_SEMANTICS)) rc = lio_members_resize(c, n);   // one resize per frame
   return rc;
 }
 
@@ -1320,13 +1343,20 @@ int pcm_obs_model(pcm_ctx* c, const pcm_lio_state* s, int extrinsic_est_en, int 
     c->lio_planes_valid = false;
     if (!rematch) { c->err = "pcm_obs_model(rematch=0) on a new scan"; return PCM_ERR_INVALID_ARGUMENT; }
   }
+  const bool ref = (c->cfg.flags & PCM_FLAG_LIO_REFERENCE_SEMANTICS) != 0;
+  if (ref) {
+    rc = lio_members_resize(c, n);
+    if (rc != PCM_OK) return rc;
+  }
   Geom geom = pick_geom(n, 1);
   KernelParams kp = kernel_params(c->cfg, geom);
   kp.lio_rematch = rematch ? 1 : 0;
   kp.lio_extrinsic = extrinsic_est_en ? 1 : 0;
+  kp.lio_ref = !ref ? 0 : ((c->cfg.sort_source && c->src_sorted) ? 2 : 1);
   PairDesc d;
   fill_desc(c, &d, w->d_partials);
   d.lio = L;
+  d.lio_aux = c->lio_aux;
   PairState ps;
   const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   init_state(ps, ident);
@@ -1430,6 +1460,22 @@ int pcm_get_planes(pcm_ctx* c, float* out, size_t n) {
   CHECK_CTX(c);
   if (!out || n != c->src.n || !c->planes) { c->err = "pcm_get_planes: call pcm_linearize first; n must equal the source size"; return PCM_ERR_INVALID_ARGUMENT; }
   HIPCK(c, hipMemcpy(out, c->planes, sizeof(float4) * n, hipMemcpyDeviceToHost));
+  return PCM_OK;
+}
+
+int pcm_get_lio_members(pcm_ctx* c, float* residuals, uint8_t* selected, size_t n) {
+  CHECK_CTX(c);
+  if (!(c->cfg.flags & PCM_FLAG_LIO_REFERENCE_SEMANTICS) || !c->lio_aux || n != c->lio_aux_n || n != c->src.n) {
+    c->err = "pcm_get_lio_members: needs PCM_FLAG_LIO_REFERENCE_SEMANTICS and n equal to the source size";
+    return PCM_ERR_INVALID_ARGUMENT;
+  }
+  std::vector<float2> tmp(n);
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  if (n) HIPCK(c, hipMemcpy(tmp.data(), c->lio_aux, sizeof(float2) * n, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; i++) {
+    if (residuals) residuals[i] = tmp[i].x;
+    if (selected) selected[i] = tmp[i].y != 0.f ? 1 : 0;
+  }
   return PCM_OK;
 }
 

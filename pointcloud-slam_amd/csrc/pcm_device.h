@@ -196,6 +196,7 @@ struct PairDesc {
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
   LioPose lio;          // LIO measurement model only
   uint32_t* nn;         // LIO: [N][5] neighbour indices into tgt.pts (~0u: none) from the last matching call
+  float2* lio_aux;      // LIO reference semantics: residuals_[i] (.x) and point_selected_surf_[i] (.y != 0) in the caller's scan order
   int32_t* corr;        // NDT / VGICP: [elements][offsets] matched target voxel (or -1) of the last linearize; GICP: [N] matched target point
   const double* src_cov;   // GICP / VGICP: [N][6] regularised covariance of every source point (xx xy xz yy yz zz)
   const double* tgt_cov;   // GICP: [M][6] of every map point (map order)
@@ -227,6 +228,8 @@ struct KernelParams {
   int32_t do_step;            // 1: k_finish_round runs the GN/LM step; 0: it exports the sums (parity hooks)
   int32_t lio_rematch;        // LIO: ekfom_data.converge (1: search + plane fit, 0: re-use the stored planes)
   int32_t lio_extrinsic;      // LIO: extrinsic_est_en (columns 6..11 of h_x)
+  int32_t lio_ref;            // LIO: 0 clean semantics; reference semantics with the per-point members indexed by the tile position (1) or by
+                              //      the scan position kept in the point's w (2: the scan was re-ordered on device)
   int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)
   int32_t coord_mode;         // CoordMode of the target map (GICP / VGICP kernels)
   int32_t use_list;           // 1: the grid's pair axis indexes `active` (only pairs the host still believes active are launched)

@@ -100,6 +100,7 @@ void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairSta
 void launch_linearize_fused(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, unsigned char* d_flags_row);
 void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp);
 void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out);
+void launch_lio_members_init(hipStream_t stream, float2* aux, uint32_t first, uint32_t last);   // entries [first, last) = (residual 0, selected)
 void launch_trial(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs);
 void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, bool trial_round,
                          bool write_flags, unsigned char* d_flags_row, double* d_sums, unsigned int* d_queue = nullptr, int total_pairs = 0);
@@ -163,6 +164,8 @@ struct pcm_ctx {
   size_t nn_cap = 0;
   uint32_t next_seq = 0;           // next insertion sequence number of the target point log
   bool lio_planes_valid = false;   // planes of the last pcm_obs_model(rematch=1) belong to the current scan
+  float2* lio_aux = nullptr;       // PCM_FLAG_LIO_REFERENCE_SEMANTICS: residuals_ / point_selected_surf_ of LaserMapping, in the caller's scan order;
+  size_t lio_aux_n = 0, lio_aux_cap = 0;   // they outlive the scan (std::vector::resize semantics, laser_mapping.cc:337-338)
   void* ws = nullptr;   // batch workspace owned by this context (pcm_api.hip)
   char* pre_arena = nullptr;   // grow-only device scratch of the pre-processing operators
   size_t pre_arena_cap = 0;

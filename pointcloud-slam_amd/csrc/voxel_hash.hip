@@ -413,7 +413,10 @@ __global__ void k_batch_gather(const SortJob* __restrict__ jobs, const uint64_t*
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= total) return;
   const SortJob job = jobs[(uint32_t)(keys_sorted[g] >> 32)];
-  gstore4(job.dst + (g - job.offset), gload4(job.src + (vals_sorted[g] - job.offset)));
+  const uint32_t from = vals_sorted[g] - job.offset;
+  float4 v = gload4(job.src + from);
+  v.w = __uint_as_float(from);   // position in the caller's scan: per-point state that outlives a frame is kept in that order
+  gstore4(job.dst + (g - job.offset), v);
 }
 
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,

@@ -163,6 +163,12 @@ class Registration:
         self._check(self._L.pcm_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), C.byref(out)))
         return np.array(out.HTH[:]).reshape(12, 12), np.array(out.HTh[:]), out.n_eff, out.sum_h2, bool(out.valid)
 
+    def get_lio_members(self, n: int):
+        """(residuals_, point_selected_surf_) as the last obs_model left them (reference-semantics mode only)."""
+        res = np.zeros(n, np.float32); sel = np.zeros(n, np.uint8)
+        self._check(self._L.pcm_get_lio_members(self._h, res.ctypes.data, sel.ctypes.data, n))
+        return res, sel.astype(bool)
+
     def target_insert(self, cloud):
         """IVox::AddPoints: append points to the sliding submap (LRU beyond map_capacity voxels)."""
         ptr, n, stride, mem, keep = _points(cloud)

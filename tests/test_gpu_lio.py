@@ -51,6 +51,57 @@ def test_obs_model_consistent_with_linearize(pcm, synth):
     assert rel_err(HTH[:3, :3], H[3:, 3:]) < 1e-5
 
 
+@pytest.mark.parametrize("sort_source", [0, 1])
+def test_obs_model_reference_semantics_across_calls_and_frames(pcm, synth, sort_source):
+    """PCM_FLAG_LIO_REFERENCE_SEMANTICS: residuals_ / point_selected_surf_ live on as LaserMapping's members do
+    (laser_mapping.cc:335-339, 616-636).  Three frames of different sizes, several ObsModel calls each with poses far
+    enough from the truth that many selected points fail `|p_body| > 81 pd2^2`: in the reference such a point stays
+    selected and contributes the residual stored for its index earlier (0 if never, or the one a previous FRAME left);
+    in the clean mode it is dropped.  The two modes must differ, and the GPU must equal the oracle in both."""
+    from oracle import Oracle
+    scene = synth.scene_for_points(4242, 60000, 8.0)
+    submap = synth.sample_submap(scene, 60000, 99)
+    T = synth.sensor_pose(scene, 5)
+    kw = dict(voxel_resolution=0.5, num_neighbors=27)
+    o_ref = Oracle("P2PLANE", "GN", **kw); o_ref.set_lio_reference_semantics(True)
+    o_cln = Oracle("P2PLANE", "GN", **kw)
+    g_ref = pcm.P2PlaneRegistration(0, sort_source=sort_source, flags=pcm.capi.PCM_FLAG_LIO_REFERENCE_SEMANTICS, **kw)
+    g_cln = pcm.P2PlaneRegistration(0, sort_source=sort_source, **kw)
+    for r in (o_ref, o_cln, g_ref, g_cln):
+        r.set_input_target(submap)
+    differ = 0
+    stale_used = 0
+    for f, npts in enumerate((5000, 3000, 6000)):       # shrink, then grow past the first frame: resize() semantics
+        scan, _ = synth.livox_scan(scene, T, npts, 700 + f)
+        for r in (o_ref, o_cln, g_ref, g_cln):
+            r.set_input_source(scan)
+        n = scan.shape[0]
+        # the IEKF's pattern (esekfom.hpp:1529,1722-1732): the first call matches; later ones may not
+        steps = ((0.45, True), (0.05, False), (0.40, False), (0.30, True), (0.02, False))
+        for k, (off, conv) in enumerate(steps):
+            Tk = T.copy(); Tk[:3, 3] += off * np.array([0.6, -0.5, 0.62]) * (1 if (k + f) % 2 == 0 else -1)
+            st = _state(Tk)
+            res_before = o_ref.get_lio_members(n)[1].copy()
+            ref_o = o_ref.obs_model(*st, True, conv)
+            cln_o = o_cln.obs_model(*st, True, conv)
+            ref_g = g_ref.obs_model(*st, True, conv)
+            cln_g = g_cln.obs_model(*st, True, conv)
+            for (H0, h0, n0, s0), (H1, h1, n1, s1, valid) in ((ref_o, ref_g), (cln_o, cln_g)):
+                assert n1 == n0 and valid and n0 > 500
+                assert rel_err(H1, H0) < HB_RTOL and rel_err(h1, h0) < HB_RTOL and abs(s1 - s0) <= HB_RTOL * max(s0, 1e-30)
+            pl_o, res_o, sel_o = o_ref.get_lio_members(n)
+            res_g, sel_g = g_ref.get_lio_members(n)
+            assert np.array_equal(sel_g, sel_o)
+            assert np.array_equal(res_g.view(np.uint32), res_o.view(np.uint32))      # residuals_: bit for bit
+            differ += ref_o[2] != cln_o[2]
+            # a selected point whose residual did not move in this call contributed a stale one
+            stale = sel_o & (res_o == res_before) & (res_o != 0)
+            stale_used += int(stale.sum())
+            assert ref_o[2] >= cln_o[2]
+    assert differ >= 6          # the modes really are different operators on this sequence
+    assert stale_used > 100     # and non-zero residuals of earlier calls / frames were re-used
+
+
 def test_obs_model_errors(pcm, synth):
     p = synth.make_pair(2, 2000, 20000)
     g = pcm.P2PlaneRegistration(0)
