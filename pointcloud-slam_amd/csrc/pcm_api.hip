@@ -1427,9 +1427,10 @@ int pcm_map_incremental(pcm_ctx* c, const pcm_lio_state* s, float filter_size_ma
   LioStateD L;
   for (int a = 0; a < 4; a++) { L.rot[a] = s->rot[a]; L.off_R[a] = s->off_R[a]; }
   for (int a = 0; a < 3; a++) { L.pos[a] = s->pos[a]; L.off_T[a] = s->off_T[a]; }
-  const float4* scan = (c->cfg.sort_source && c->src_sorted) ? c->src_order : c->src.d_pts;
+  const bool reordered = c->cfg.sort_source && c->src_sorted;
+  const float4* scan = reordered ? c->src_order : c->src.d_pts;
   uint32_t added = 0;
-  rc = map_incremental_device(c->stream, scan, n, L, filter_size_map, have_nn ? c->nn : nullptr, have_nn ? c->map.pts : nullptr, c->next_seq,
+  rc = map_incremental_device(c->stream, scan, reordered, n, L, filter_size_map, have_nn ? c->nn : nullptr, have_nn ? c->map.pts : nullptr, c->next_seq,
                               c->tgt.d_pts + c->tgt.n, &added, &c->err);
   if (rc != PCM_OK) return rc;
   c->tgt.n += added;

@@ -74,8 +74,8 @@ struct SortScratch {
 };
 // MapIncremental on the device (voxel_hash.hip)
 struct LioStateD { double rot[4], pos[3], off_R[4], off_T[3]; };
-int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, const LioStateD& s, float filter_size_map, const uint32_t* nn, const float4* map_pts,
-                           uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err);
+int map_incremental_device(hipStream_t stream, const float4* scan, bool scan_reordered, uint32_t n, const LioStateD& s, float filter_size_map, const uint32_t* nn,
+                           const float4* map_pts, uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err);
 // preprocess.hip
 int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride, size_t time_off, const pcm_imu_pose* d_poses, int npose, const LioStateD& s, std::string* err);
 size_t voxel_downsample_scratch_bytes(size_t n);

@@ -472,10 +472,13 @@ __device__ inline void qrot_d(const double* q, const double* v, double* r) {   /
 
 // flag[i]: 0 = not added, 1 = points_to_add, 2 = point_no_need_downsample; world[i] = PointBodyToWorld(scan[i])
 __global__ void k_map_filter(const float4* __restrict__ scan, uint32_t n, LioStateD s, float fs, const uint32_t* __restrict__ nn, const float4* __restrict__ map_pts,
-                             float4* __restrict__ world, uint32_t* __restrict__ f1, uint32_t* __restrict__ f2) {
+                             float4* __restrict__ world, uint32_t* __restrict__ f1, uint32_t* __restrict__ f2, int scan_reordered) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 pb = scan[i];
+  // the verdicts are laid out in the order of the caller's scan (a re-ordered scan carries that position in w): the order in
+  // which points enter the map decides their voxels' places in the LRU list
+  const uint32_t o = scan_reordered ? __float_as_uint(pb.w) : i;
   // p_global = rot * (offset_R_L_I * p_body + offset_T_L_I) + pos   in double   laser_mapping.cc:855-864
   const double vb[3] = {(double)pb.x, (double)pb.y, (double)pb.z};
   double v1[3], v2[3];
@@ -483,7 +486,7 @@ __global__ void k_map_filter(const float4* __restrict__ scan, uint32_t n, LioSta
   for (int a = 0; a < 3; a++) v1[a] += s.off_T[a];
   qrot_d(s.rot, v1, v2);
   const float pw[3] = {(float)(v2[0] + s.pos[0]), (float)(v2[1] + s.pos[1]), (float)(v2[2] + s.pos[2])};
-  world[i] = make_float4(pw[0], pw[1], pw[2], 0.f);
+  world[o] = make_float4(pw[0], pw[1], pw[2], 0.f);
   uint32_t flag = 1;
   if (nn != nullptr && nn[(size_t)i * 5] != ~0u) {   // !nearest_points_[i].empty() && flg_EKF_inited_
     float center[3];
@@ -507,8 +510,8 @@ __global__ void k_map_filter(const float4* __restrict__ scan, uint32_t n, LioSta
       flag = need_add ? 1u : 0u;
     }
   }
-  f1[i] = flag == 1 ? 1u : 0u;
-  f2[i] = flag == 2 ? 1u : 0u;
+  f1[o] = flag == 1 ? 1u : 0u;
+  f2[o] = flag == 2 ? 1u : 0u;
 }
 
 __global__ void k_map_append(const float4* __restrict__ world, const uint32_t* __restrict__ f1, const uint32_t* __restrict__ f2, const uint32_t* __restrict__ p1,
@@ -519,8 +522,8 @@ __global__ void k_map_append(const float4* __restrict__ world, const uint32_t* _
   if (f2[i]) { float4 v = world[i]; v.w = __uint_as_float(seq0 + n1 + p2[i]); out[n1 + p2[i]] = v; }       // then point_no_need_downsample
 }
 
-int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, const LioStateD& s, float filter_size_map, const uint32_t* nn, const float4* map_pts,
-                           uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err) {
+int map_incremental_device(hipStream_t stream, const float4* scan, bool scan_reordered, uint32_t n, const LioStateD& s, float filter_size_map, const uint32_t* nn,
+                           const float4* map_pts, uint32_t seq0, float4* out_append, uint32_t* num_added, std::string* err) {
   float4* world = nullptr;
   uint32_t* buf = nullptr;   // f1, f2, p1, p2
   void* tmp = nullptr;
@@ -536,7 +539,7 @@ int map_incremental_device(hipStream_t stream, const float4* scan, uint32_t n, c
   CK(hipMallocAsync(&buf, sizeof(uint32_t) * 4 * (size_t)n, stream));
   {
     uint32_t *f1 = buf, *f2 = buf + n, *p1 = buf + 2 * (size_t)n, *p2 = buf + 3 * (size_t)n;
-    k_map_filter<<<cdiv(n, 256), 256, 0, stream>>>(scan, n, s, filter_size_map, nn, map_pts, world, f1, f2);
+    k_map_filter<<<cdiv(n, 256), 256, 0, stream>>>(scan, n, s, filter_size_map, nn, map_pts, world, f1, f2, scan_reordered ? 1 : 0);
     CK(hipGetLastError());
     CK(rocprim::exclusive_scan(nullptr, tmp_bytes, f1, p1, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
     CK(hipMallocAsync(&tmp, tmp_bytes, stream));

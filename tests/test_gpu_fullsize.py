@@ -1,0 +1,132 @@
+"""Parity against the oracle at BASELINE.json's full sizes: the sizes the bench line is quoted on,
+not the 10k / 100k plumbing case.
+
+  config 2   one 100k-pt Livox-shaped scan vs a 1M-pt submap, point-to-plane, GN and LM
+  config 4   one pclomp-NDT registration of a 100k-pt scan on the 0.5 m grid of a 10M-pt map, transformation epsilon 0.01
+             (the setting of the call sites: jueying_slam/src/localization.cpp:170-175)
+  config 5   20 frames of the jueying_lio loop (ObsModel -> MapIncremental) on a ~5M-pt sliding submap held at the IVox
+             capacity of 1,000,000 voxels (ivox3d.h:57), against oracle/orc_lru.c point for point
+
+The oracle needs seconds for each at these sizes; the whole file runs in a few minutes on the GPU box.
+"""
+import numpy as np
+import pytest
+
+from helpers import HB_RTOL, POSE_TOL_M, POSE_TOL_RAD, pose_error, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("optimizer", ["GN", "LM"])
+def test_config2_pair_100k_vs_1m_matches_oracle(pcm, synth, optimizer):
+    from oracle import Oracle
+    from oracle.loader import result_T
+    p = synth.make_pair(3, 100000, 1000000)
+    o = Oracle("P2PLANE", optimizer)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g = pcm.P2PlaneRegistration(0, optimizer=optimizer)
+    g.set_input_target(p.submap); g.set_input_source(p.scan)
+    ro, rg = o.align(p.guess), g.align(p.guess)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)          # 1e-4 m / 1e-4 rad (north_star); measured ~1e-10
+    assert rg.iterations == ro.iterations and rg.converged == bool(ro.converged) and rg.converged
+    assert rg.num_inliers == ro.num_inliers and rg.num_inliers > 80000   # the selected sets are the same sets
+    assert rel_err(rg.H, np.array(ro.H[:]).reshape(6, 6)) < HB_RTOL
+    # and the linearisation itself at the start pose, sum for sum
+    c0, H0, b0 = o.linearize(p.guess); n0 = o.num_inliers
+    c1, H1, b1, n1 = g.evaluate_cost(p.guess)
+    assert n1 == n0 and rel_err(H1, H0) < HB_RTOL and rel_err(b1, b0) < HB_RTOL and abs(c1 - c0) <= HB_RTOL * c0
+    dgt = pose_error(rg.T64, p.T_gt)
+    assert dgt[0] < 0.05 and dgt[1] < 2e-3                           # and it is the right pose, not just the same one
+
+
+def test_config4_ndt_100k_scan_on_10m_point_grid_matches_oracle(pcm, synth):
+    from oracle import Oracle
+    from oracle.loader import result_T
+    p = synth.make_pair(0, 100000, 10_000_000, density=60.0)          # 0.5 m leaves need >= 6 points each
+    g = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=7, translation_eps=0.01)
+    cfg = g.config
+    o = Oracle("NDT_OMP", "LM", voxel_resolution=0.5, num_neighbors=7, translation_eps=0.01, max_iterations=cfg.max_iterations,
+               ndt_step_size=float(cfg.ndt_step_size), ndt_outlier_ratio=float(cfg.ndt_outlier_ratio))
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g.set_input_target(p.submap); g.set_input_source(p.scan)
+    ro, rg = o.align(p.guess), g.align(p.guess)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+    assert rg.iterations == ro.iterations and rg.converged == bool(ro.converged)
+    assert rg.num_linearize == ro.num_linearize and rg.num_compute_error == ro.num_compute_error
+    assert rel_err(rg.H, np.array(ro.H[:]).reshape(6, 6)) < 1e-5
+    assert abs(g.ndt_score(rg.T) - o.ndt_score(rg.T)) <= 1e-12 * abs(o.ndt_score(rg.T))   # calculateScore at the result
+    e0, e1 = pose_error(p.guess, p.T_gt), pose_error(rg.T64, p.T_gt)
+    assert e1[0] < 0.5 * e0[0]                                           # epsilon 0.01 stops early, but it did register
+
+
+def sliding_map_scenario(synth, n_frames=20, scan_points=20000, capacity=1_000_000, res=0.5):
+    """A sensor driving 1.5 m per frame towards unmapped ground.  The map is what lies behind a frontier 30 m ahead of
+    the first pose and not further back than the distance at which it fills capacity - 3000 voxels (about 5.4M points):
+    every frame then opens new voxels, and the LRU starts evicting within the first frames."""
+    scene = synth.scene_for_points(2024, 8_000_000, 22.0)
+    allpts = synth.sample_submap(scene, 8_000_000, 11)
+
+    def free(xy, m=1.0):
+        x, y = xy
+        inside = np.any((scene.boxes[:, 0] - m < x) & (x < scene.boxes[:, 3] + m) & (scene.boxes[:, 1] - m < y) & (y < scene.boxes[:, 4] + m))
+        inside |= bool(np.any(np.hypot(scene.cyls[:, 0] - x, scene.cyls[:, 1] - y) < scene.cyls[:, 2] + m))
+        return not inside
+
+    for seed in range(400):
+        T0 = synth.sensor_pose(scene, seed)
+        fwd = T0[:3, 0].copy(); fwd[2] = 0.0; fwd /= np.linalg.norm(fwd)
+        if not all(free(T0[:2, 3] + fwd[:2] * d) for d in np.arange(0.0, 1.5 * n_frames + 1.0, 0.5)):
+            continue
+        s = (allpts[:, :3].astype(np.float64) - T0[:3, 3]) @ fwd
+        idx = np.nonzero(s < 30.0)[0]
+        if 0.72 * len(allpts) < len(idx) < 0.9 * len(allpts):
+            break
+    else:
+        raise RuntimeError("no sensor track found")
+    idx = idx[np.argsort(-s[idx], kind="stable")]       # from the frontier backwards
+    key = np.round(allpts[idx, :3] / np.float32(res)).astype(np.int64)
+    key = (key[:, 0] + (1 << 20)) | ((key[:, 1] + (1 << 20)) << 21) | ((key[:, 2] + (1 << 20)) << 42)
+    _, first = np.unique(key, return_index=True)
+    opens = np.zeros(len(idx), bool); opens[first] = True
+    nvox = np.cumsum(opens)
+    n_map = int(np.searchsorted(nvox, capacity - 3000))
+    assert n_map < len(idx), "the region behind the frontier does not fill the capacity"
+    submap = np.ascontiguousarray(allpts[np.sort(idx[:n_map])])
+    frames = []
+    for f in range(n_frames):
+        Tf = T0.copy(); Tf[:3, 3] += fwd * 1.5 * f
+        scan, _ = synth.livox_scan(scene, Tf, scan_points, 900 + f)
+        frames.append((Tf, scan))
+    return submap, frames
+
+
+def test_config5_twenty_frames_on_a_sliding_map_at_ivox_capacity(pcm, synth):
+    from oracle import Oracle
+    from test_gpu_lio import _state
+    cap = 1_000_000
+    submap, frames = sliding_map_scenario(synth, capacity=cap)
+    assert 4_000_000 < len(submap) < 7_000_000
+    kw = dict(voxel_resolution=0.5, num_neighbors=27, map_capacity=cap)
+    o = Oracle("P2PLANE", "GN", **kw)
+    g = pcm.P2PlaneRegistration(0, **kw)
+    o.set_input_target(submap); g.set_input_target(submap)
+    sizes = [len(submap)]
+    evicting_frames = 0
+    for f, (Tf, scan) in enumerate(frames):
+        st = _state(Tf)
+        o.set_input_source(scan); g.set_input_source(scan)
+        H0, h0, n0, s0 = o.obs_model(*st, False, True)
+        H1, h1, n1, s1, valid = g.obs_model(*st, False, True)
+        assert n1 == n0 and valid and n0 > 0.5 * len(scan)
+        assert rel_err(H1, H0) < HB_RTOL and rel_err(h1, h0) < HB_RTOL
+        a0 = o.map_incremental(*st, 0.5, True)
+        a1 = g.map_incremental(*st, 0.5, True)
+        assert a1 == a0 and a0 > 0
+        got, want = g.get_target(), o.get_target()
+        assert got.shape == want.shape and np.array_equal(got, want), f"frame {f}: map content differs"
+        assert o.target_voxels <= cap
+        evicting_frames += len(want) < sizes[-1] + a0       # fewer points than before + added: voxels were dropped
+        sizes.append(len(want))
+    assert evicting_frames >= 10                             # the capacity was really in play for most of the run

@@ -115,14 +115,15 @@ def test_obs_model_errors(pcm, synth):
     assert n == 0 and not valid                 # "No Effective Points!" laser_mapping.cc:657-661
 
 
-def test_sliding_map_add_filter_matches_oracle(pcm, synth):
+@pytest.mark.parametrize("sort_source", [0, 1])      # the device's re-ordering of the scan must not show in the map
+def test_sliding_map_add_filter_matches_oracle(pcm, synth, sort_source):
     """Three LIO frames: match -> MapIncremental (add-filter against the matched neighbours) ->
     rebuilt voxel hash; the map content must equal the oracle's point for point."""
     from oracle import Oracle
     scene = synth.scene_for_points(1234, 60000, 8.0)
     submap = synth.sample_submap(scene, 60000, 4321)
     o = Oracle("P2PLANE", "GN", voxel_resolution=0.5, num_neighbors=27)
-    g = pcm.P2PlaneRegistration(0, voxel_resolution=0.5, num_neighbors=27, sort_source=0)
+    g = pcm.P2PlaneRegistration(0, voxel_resolution=0.5, num_neighbors=27, sort_source=sort_source)
     o.set_input_target(submap); g.set_input_target(submap)
     T = synth.sensor_pose(scene, 77)
     for f in range(3):
