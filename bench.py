@@ -10,6 +10,10 @@ resident in HBM and the submap voxel hashes are built before the timed region
 (the reference's `100times_reuse` protocol, fast_gicp/src/align.cpp:51-104);
 the cold rate (hash build included) is reported next to it.
 
+Schedule (default `--schedule rotate --pipeline 2`): two passes are in flight per GPU, pass s on slot s % 2, each slot
+with registration objects, stream and result block of its own -- the few slow-converging pairs of one pass (59 GN
+iterations where the mean is 12) finish under the bulk of the next.  The timed region is EXACTLY `--steps` passes.
+
 Prints ONE JSON line (rank 0).  Launch for N>1 with torch.distributed.run.
 """
 from __future__ import annotations
@@ -102,10 +106,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs-per-gpu", type=int, default=32)
+    ap.add_argument("--pairs-per-gpu", type=int, default=64, help="registrations per step and GPU (one batch = one step)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="independent batches in flight per GPU (each on its own stream / host thread), so the few slow-converging "
                          "pairs of one batch run under the bulk of the next")
+    ap.add_argument("--schedule", default="rotate", choices=["rotate", "split"],
+                    help="rotate: pass s of the whole batch runs on slot s %% pipeline (every slot sees the same mix of fast and slow pairs); "
+                         "split: every pass is split into fixed sub-batches, one per slot (round 1; the slot holding the slowest pair is the critical path)")
     ap.add_argument("--window", type=int, default=0, help="pairs of a sub-batch iterating at a time (0 = all): finished pairs hand their slot to queued ones")
     ap.add_argument("--flags", type=int, default=0, help="pcm_config.flags (A/B switches; never change a result)")
     ap.add_argument("--scan-points", type=int, default=100000)
@@ -113,7 +120,7 @@ def main():
     ap.add_argument("--optimizer", default="GN", choices=["GN", "LM"])
     ap.add_argument("--max-iterations", type=int, default=64)
     ap.add_argument("--sort-source", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=0)
     ap.add_argument("--slot-priority", type=int, default=0, help="1: the pipeline slots run on streams of descending priority (slot 0 highest), so the "
                     "tail rounds of one slot are not queued behind the bulk of another")
@@ -156,37 +163,43 @@ def main():
             dist.init_process_group("gloo")
 
     # ---- residency: scans + submaps in HBM, voxel hashes built ------------------------------------
-    regs, guesses = [], []
-    d_inputs = []
-    for scan, submap, guess, _ in pairs:
-        d_scan = torch.from_numpy(scan).to(dev)
-        d_map = torch.from_numpy(submap).to(dev)
-        d_inputs.append((d_scan, d_map))
-        r = pcm.P2PlaneRegistration(dev_index, optimizer=args.optimizer, voxel_resolution=cfg["voxel_resolution"],
-                                    num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source, batch_window=args.window, flags=args.flags)
-        r.set_input_target(d_map)
-        r.set_input_source(d_scan)
-        regs.append(r)
-        guesses.append(guess)
-    guesses = np.stack(guesses)
-    n_local = len(regs)
-    rec = ctypes.sizeof(capi.PcmResult)
-    d_results = torch.zeros(n_local * rec, dtype=torch.uint8, device=dev)
-    d_gather = torch.zeros(world * n_local * rec, dtype=torch.uint8, device=dev) if world > 1 else None
-
-    # ---- S independent sub-batches per GPU, each driven by its own host thread on its own stream ----
     import threading
     from pointcloud_slam_amd import sharding
-    groups = sharding.split_sub_batches(n_local, args.pipeline)
-    S = len(groups)
+    rotate = args.schedule == "rotate"
+    n_local = len(pairs)
+    S = max(1, min(args.pipeline, n_local))
+    groups = sharding.split_sub_batches(n_local, S)       # split schedule: the pairs of slot j
+    n_sets = S if rotate else 1                            # rotate: every slot registers the whole batch with objects of its own
+    d_inputs = []
+    guesses = np.stack([guess for _, _, guess, _ in pairs])
+    for scan, submap, _, _ in pairs:
+        d_inputs.append((torch.from_numpy(scan).to(dev), torch.from_numpy(submap).to(dev)))
+    reg_sets = []
+    for _ in range(n_sets):
+        regs = []
+        for d_scan, d_map in d_inputs:
+            r = pcm.P2PlaneRegistration(dev_index, optimizer=args.optimizer, voxel_resolution=cfg["voxel_resolution"],
+                                        num_neighbors=cfg["num_neighbors"], max_iterations=args.max_iterations, sort_source=args.sort_source, batch_window=args.window, flags=args.flags)
+            r.set_input_target(d_map)
+            r.set_input_source(d_scan)
+            regs.append(r)
+        reg_sets.append(regs)
+    regs = reg_sets[0]
+    rec = ctypes.sizeof(capi.PcmResult)
+    # result blocks: split -> one block of n_local records, slot j owns its slice; rotate -> one block of n_local records per slot
+    d_results = torch.zeros(n_sets * n_local * rec, dtype=torch.uint8, device=dev)
+    d_gather = torch.zeros(n_sets * world * n_local * rec, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    # ---- S batches in flight per GPU, each driven by its own host thread on its own stream ----
+    lead = [reg_sets[j][0] if rotate else regs[groups[j][0]] for j in range(S)]    # the object whose stream / statistics a slot's batches use
     slot_streams = []
     if args.slot_priority:
         lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
         for j in range(S):
             st_j = torch.cuda.Stream(device=dev, priority=(hi_p if j == 0 else lo_p))
             slot_streams.append(st_j)
-            for i in groups[j]:
-                regs[i].set_stream(st_j.cuda_stream)
+            for r in (reg_sets[j] if rotate else [regs[i] for i in groups[j]]):
+                r.set_stream(st_j.cuda_stream)
     # ONE communicator (the default group) and ONE thread that issues every collective, in the order (step, slot) -- the same on
     # every rank by construction.  (Round 1 gave each pipeline slot its own communicator and let the slot threads issue their
     # gathers as they finished: rank A could enqueue slot 0 then 1 while rank B enqueued 1 then 0, the documented way to hang
@@ -199,29 +212,40 @@ def main():
         torch.cuda.synchronize()
 
     def sub_step(j, before_results=None):
-        """One pass of the hot path over sub-batch j."""
-        idx = groups[j]
-        lo, hi = idx[0], idx[-1] + 1
+        """One pass of the hot path on slot j: over the whole batch (rotate) or over sub-batch j (split)."""
+        if rotate:
+            mine, lo, hi, out_ptr = reg_sets[j], 0, n_local, d_results.data_ptr() + j * n_local * rec
+        else:
+            idx = groups[j]
+            lo, hi = idx[0], idx[-1] + 1
+            mine, out_ptr = [regs[i] for i in idx], d_results.data_ptr() + lo * rec
         # a registration starts from a NEW scan: hand every object its (HBM-resident) scan
         # again, so the on-device Morton re-ordering is inside the timed step
-        for i in idx:
-            regs[i].set_input_source(d_inputs[i][0])
+        for k, r in enumerate(mine):
+            r.set_input_source(d_inputs[lo + k][0])
         if before_results is not None:
             before_results()     # the gather of this slot's previous result block has been issued and has finished
-        return pcm.align_batch([regs[i] for i in idx], guesses[lo:hi], device_out=d_results.data_ptr() + lo * rec)
+        return pcm.align_batch(mine, guesses[lo:hi], device_out=out_ptr)
 
     def gather_slot(j):
         """RCCL all-gather of slot j's solved poses over xGMI (one small collective), complete on return."""
-        lo, hi = groups[j][0], groups[j][-1] + 1
         with torch.cuda.stream(comm_stream):
-            got = sharding.gather_records(d_results[lo * rec:hi * rec], world)
-            d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got)
+            if rotate:
+                got = sharding.gather_records(d_results[j * n_local * rec:(j + 1) * n_local * rec], world)
+                d_gather.view(S, world, n_local * rec)[j].copy_(got.view(world, n_local * rec))
+            else:
+                lo, hi = groups[j][0], groups[j][-1] + 1
+                got = sharding.gather_records(d_results[lo * rec:hi * rec], world)
+                d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got)
         comm_stream.synchronize()
 
     def run_steps(k, stagger_s=0.0):
-        """k passes over every sub-batch (sharding.run_pipelined_steps: slot threads for the compute, one thread for the collectives)."""
-        last = sharding.run_pipelined_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s,
-                                            on_thread_start=lambda: torch.cuda.set_device(dev_index))
+        """k passes over the batch; returns the results of the last one (sharding.run_rotating_steps / run_pipelined_steps:
+        slot threads for the compute, one thread for the collectives)."""
+        kw = dict(on_thread_start=lambda: torch.cuda.set_device(dev_index))
+        if rotate:
+            return sharding.run_rotating_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s, **kw)
+        last = sharding.run_pipelined_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s, **kw)
         return [r for grp in last for r in grp]
 
     def fence():
@@ -230,31 +254,35 @@ def main():
             dist.barrier(**bar_kw)
             torch.cuda.synchronize()
 
-    # cold pass: includes voxel-hash build + scan re-ordering (lazy on first align)
+    # cold pass: includes voxel-hash build + scan re-ordering (lazy on first align); rotate: one pass per slot, so that every
+    # slot's objects have built their maps before the timed region
+    per = S if rotate else 1
     fence()
     t0 = time.perf_counter()
-    res = run_steps(1)
+    res = run_steps(per)
     fence()
-    t_cold = time.perf_counter() - t0
+    t_cold = (time.perf_counter() - t0) / per
 
     t0 = time.perf_counter()
     for _ in range(max(1, args.warmup - 1)):
-        run_steps(1)
+        run_steps(per)
     fence()
-    t_warm = (time.perf_counter() - t0) / max(1, args.warmup - 1)
+    t_warm = (time.perf_counter() - t0) / (max(1, args.warmup - 1) * per)
 
     for j in range(S):
-        regs[groups[j][0]].reset_stats()
-        regs[groups[j][0]].set_profiling(1)         # HIP events around every residual launch, on the launch stream
+        lead[j].reset_stats()
+        # HIP events around every 4th residual launch, on the launch stream (bit3: sampled, the phase rotating from batch to batch:
+        # bracketing EVERY launch costs 16 % of the headline -- three events on the critical path of every round)
+        lead[j].set_profiling(int(os.environ.get("PCM_BENCH_LAUNCH_EVENTS", "9")))
     fence()
     t0 = time.perf_counter()
     res = run_steps(args.steps, stagger_s=args.stagger * t_warm if S > 1 else 0.0)
     fence()
     elapsed = time.perf_counter() - t0
-    sts = [regs[groups[j][0]].stats() for j in range(S)]
+    sts = [lead[j].stats() for j in range(S)]
     st = {k: sum(x[k] for x in sts) for k in sts[0]}
     for j in range(S):
-        regs[groups[j][0]].set_profiling(0)
+        lead[j].set_profiling(0)
 
     t = torch.tensor([elapsed, t_cold], dtype=torch.float64, device=dev)
     if world > 1:
@@ -263,20 +291,20 @@ def main():
 
     # counters pass (untimed): candidates / probes per point for the algorithmic-byte model
     for j in range(S):
-        regs[groups[j][0]].reset_stats()
-        regs[groups[j][0]].set_profiling(3)
-    run_steps(1)
-    scs = [regs[groups[j][0]].stats() for j in range(S)]
+        lead[j].reset_stats()
+        lead[j].set_profiling(3)
+    run_steps(S if rotate else 1)
+    scs = [lead[j].stats() for j in range(S)]
     sc = {k: sum(x[k] for x in scs) for k in scs[0]}
     for j in range(S):
-        regs[groups[j][0]].set_profiling(0)
+        lead[j].set_profiling(0)
     kbar = sc["candidates"] / max(1, sc["point_passes"])
     probes = sc["slots_probed"] / max(1, sc["point_passes"])
 
     gathered_ok = None
     if world > 1:   # untimed check of the exchange: own block round-trips, every rank's poses arrived
-        allrec = d_gather.view(world, n_local * rec)
-        if not torch.equal(allrec[rank], d_results):
+        allrec = d_gather.view(n_sets, world, n_local * rec)[0]
+        if not torch.equal(allrec[rank], d_results[:n_local * rec]):
             raise SystemExit("rank %d: gathered block differs from the local results" % rank)
         gathered_ok = sum(int(r["status"] == 0) for r in sharding.records_to_results(allrec.reshape(-1)))
 
@@ -288,8 +316,11 @@ def main():
     # = query float4 + 27 hash slots + K-bar candidate float4s  (SURVEY.md §8d, P2PLANE exact 5-NN row)
     b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
     launches = max(1, st["linearize_launches"])
-    bytes_per_launch = st["point_passes"] * b_pi / launches
-    avg_launch_ms = st["linearize_ms"] / launches
+    timed = max(1, st["timed_launches"])
+    # the timed launches' share of the point passes: by the length of their pair lists
+    share = st["timed_pair_slots"] / max(1, st["launched_pair_slots"])
+    bytes_per_launch = st["point_passes"] * share * b_pi / timed
+    avg_launch_ms = st["linearize_ms"] / timed
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -312,16 +343,16 @@ def main():
             "dtype": "f32 geometry / f64 accumulate", "data": "synthetic",
             "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence)"
                                    % (args.scan_points, args.map_points, args.optimizer),
-                       "pairs_per_gpu": n_local, "batches_in_flight": S, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
+                       "pairs_per_gpu": n_local, "batches_in_flight": S, "schedule": args.schedule, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
                        "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_linearize", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_point_pass": b_pi, "candidates_per_point": kbar, "slots_probed_per_point": probes,
-                         "point_passes_per_launch": st["point_passes"] / launches,
+                         "point_passes_per_launch": st["point_passes"] * share / timed, "launches": launches, "launches_timed": st["timed_launches"],
                          "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]),
-                         "residual_kernel_avg_ms": st["residual_ms"] / launches},
+                         "residual_kernel_avg_ms": (st["residual_ms"] / launches) if st["residual_ms"] > 0 else None},
         }
         # the CPU leg is timed on rank 0 of the single-GPU run only (the other ranks would idle behind it)
         out["cpu_baseline"] = None

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PCM_ABI_VERSION 1
+#define PCM_ABI_VERSION 2
 
 typedef enum pcm_status {
   PCM_OK = 0,
@@ -141,7 +141,10 @@ typedef struct pcm_stats {
   uint64_t tiles;                /* 256-point tiles searched (counter passes only) */
   uint64_t tiles_lds_grid;       /* ... whose voxel box fitted the LDS grid */
   uint64_t tiles_lds_points;     /* ... whose map points were staged through LDS as well */
-  double residual_ms;            /* HIP-event time of the residual/reduction launches */
+  double residual_ms;            /* HIP-event time of the residual/reduction launches (every-launch mode only) */
+  uint64_t timed_launches;       /* launches bracketed by HIP events (= linearize_launches unless profiling bit3 samples them) */
+  uint64_t timed_pair_slots;     /* sum of the pair-list lengths of the timed launches ... */
+  uint64_t launched_pair_slots;  /* ... and of all launches: the share of point_passes that falls to the timed ones */
 } pcm_stats;
 
 typedef struct pcm_ctx pcm_ctx;
@@ -297,7 +300,10 @@ int pcm_align_batch(pcm_ctx *const *ctxs, int n, const float *guesses, pcm_resul
 /* profiling flags: bit0 = bracket every residual launch with HIP events on the
  * launch stream (pcm_stats.linearize_ms); bit1 = collect the kNN candidate /
  * probe counters (slower kernel variant; use in an untimed pass); bit2 = in-kernel
- * phase stamps of the correspondence-search kernel (diagnostic build) */
+ * phase stamps of the correspondence-search kernel (diagnostic build); bit3 (with
+ * bit0) = bracket only every 4th launch, the phase moving from batch to batch: an
+ * event costs a few microseconds on the critical path of every round, which at one
+ * pair per round is a tenth of the round (pcm_stats.timed_launches counts them) */
 int pcm_set_profiling(pcm_ctx *ctx, int flags);
 /* diagnostic (profiling bit2): per-phase s_memtime sums of k_linearize, [7] = tiles; resets on read */
 int pcm_debug_phase_cycles(pcm_ctx *ctx, uint64_t out[8]);

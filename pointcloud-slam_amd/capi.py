@@ -65,7 +65,8 @@ class PcmStats(C.Structure):
     _fields_ = [("linearize_launches", C.c_uint64), ("point_passes", C.c_uint64),
                 ("candidates", C.c_uint64), ("slots_probed", C.c_uint64), ("linearize_ms", C.c_double),
                 ("target_voxels", C.c_uint64), ("target_slots", C.c_uint64), ("tiles", C.c_uint64),
-                ("tiles_lds_grid", C.c_uint64), ("tiles_lds_points", C.c_uint64), ("residual_ms", C.c_double)]
+                ("tiles_lds_grid", C.c_uint64), ("tiles_lds_points", C.c_uint64), ("residual_ms", C.c_double),
+                ("timed_launches", C.c_uint64), ("timed_pair_slots", C.c_uint64), ("launched_pair_slots", C.c_uint64)]
 
 
 def library_path() -> str:

@@ -349,7 +349,8 @@ void launch_finish_round(hipStream_t stream, const PairDesc* d_descs, PairState*
 // k_linearize: grid = (tiles_per_pair, pairs launched), block = 256, one scan point per lane
 // ---------------------------------------------------------------------------
 constexpr int kCapCells = 2048;   // LDS voxel grid of a tile (one uint16 per cell)
-constexpr int kCapPts = 1792;     // map points staged per tile (float4 each); keeps the workgroup under 40 KB of LDS (4 per CU)
+constexpr int kCapPts = 1536;     // map points staged per tile (float4 each); keeps the workgroup under 32 KB of LDS (5 per CU)
+constexpr int kCapJobs = 64;      // queued 3- and 4-neighbour plane fits per tile; beyond that the lane solves its own
 constexpr int kCapBricks = 64;    // bricks under a tile box
 constexpr uint16_t kNoCell = 0xffffu;
 
@@ -363,7 +364,7 @@ constexpr uint16_t kNoCell = 0xffffu;
   }
 
 template <bool STATS, bool TIMING, bool WRITE_PLANES, bool LIO, bool FUSED = false>
-__global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
+__global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
                                                       unsigned long long* __restrict__ stats, LsqParams lp = LsqParams{}, unsigned char* __restrict__ flags_row = nullptr) {
   const int pair = PCM_PAIR_OF(kp, blockIdx.y);
   if (states[pair].mode != MODE_LINEARIZE) {
@@ -390,8 +391,8 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
   __shared__ uint32_t s_njobs;
   __shared__ uint16_t s_cell[kCapCells];   // first staged point of the voxel in that cell, kNoCell when empty
   __shared__ float4 s_pts[kCapPts];        // the bricks' map points, .w = voxel tag
-  __shared__ uint32_t s_job[256];          // owner tid | m << 16
-  __shared__ uint32_t s_jobid[256][4];     // the 3 or 4 neighbour ids of the job
+  __shared__ uint32_t s_job[kCapJobs];     // owner tid | m << 16
+  __shared__ uint32_t s_jobid[kCapJobs][4];   // the 3 or 4 neighbour ids of the job
 
   uint32_t n_cand = 0, n_probe = 0;
   unsigned long long t_prev = 0;
@@ -630,34 +631,46 @@ __global__ void __launch_bounds__(256, 4) k_linearize(const PairDesc* __restrict
         else if (ok) pl = fit;
       } else if (best.m >= KMIN) {
         my_job = atomicAdd(&s_njobs, 1u);
-        s_job[my_job] = threadIdx.x | ((uint32_t)best.m << 16);
-  #pragma unroll
-        for (int j = 0; j < 4; j++) s_jobid[my_job][j] = best.i[j];
       }
     }
     PCM_STAMP(5)   // float plane fit
-    __syncthreads();
-    const uint32_t njobs = s_njobs;
-    for (uint32_t job = threadIdx.x; job < njobs; job += 256) {
-      const uint32_t m = s_job[job] >> 16;
-      float px[K], py[K], pz[K];
+    // the queue holds kCapJobs fits; a tile with more of them (a scan over nearly empty map) goes round again
+    for (uint32_t base = 0;; base += kCapJobs) {
+      if (my_job != ~0u && my_job >= base && my_job < base + kCapJobs) {
+        const uint32_t slot = my_job - base;
+        s_job[slot] = threadIdx.x | ((uint32_t)best.m << 16);
   #pragma unroll
-      for (int j = 0; j < K; j++) {
-        float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < (int)m) mp = use_lds ? s_pts[s_jobid[job][j]] : gload4(tg.pts + s_jobid[job][j]);
-        px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
+        for (int j = 0; j < 4; j++) s_jobid[slot][j] = best.i[j];
       }
-      float4 fit;
-      const bool ok = esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit);
-      if (LIO && kp.lio_ref) s_job[job] = ok ? 1u : 0u;
-      else if (!ok) fit.x = __builtin_nanf("");
-      s_jobid[job][0] = __float_as_uint(fit.x); s_jobid[job][1] = __float_as_uint(fit.y);   // hand the plane back to its owner lane
-      s_jobid[job][2] = __float_as_uint(fit.z); s_jobid[job][3] = __float_as_uint(fit.w);
-    }
-    __syncthreads();   // also: nobody reads s_pts after this point (its memory is re-used below)
-    if (my_job != ~0u) {
-      pl = make_float4(__uint_as_float(s_jobid[my_job][0]), __uint_as_float(s_jobid[my_job][1]), __uint_as_float(s_jobid[my_job][2]), __uint_as_float(s_jobid[my_job][3]));
-      if (LIO && kp.lio_ref) { ref_fit = true; ref_ok = s_job[my_job] != 0u; }
+      __syncthreads();   // also: the float fits are through with s_pts
+      const uint32_t njobs = s_njobs;   // nobody adds to it any more
+      if (base >= njobs) break;
+      const uint32_t here = min(njobs - base, (uint32_t)kCapJobs);
+      if (threadIdx.x < here) {
+        const uint32_t job = threadIdx.x;
+        const uint32_t m = s_job[job] >> 16;
+        float px[K], py[K], pz[K];
+  #pragma unroll
+        for (int j = 0; j < K; j++) {
+          float4 mp = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j < (int)m) mp = use_lds ? s_pts[s_jobid[job][j]] : gload4(tg.pts + s_jobid[job][j]);
+          px[j] = mp.x; py[j] = mp.y; pz[j] = mp.z;
+        }
+        float4 fit;
+        const bool ok = esti_plane(px, py, pz, (int)m, kp.plane_threshold, &fit);
+        if (LIO && kp.lio_ref) s_job[job] = ok ? 1u : 0u;
+        else if (!ok) fit.x = __builtin_nanf("");
+        s_jobid[job][0] = __float_as_uint(fit.x); s_jobid[job][1] = __float_as_uint(fit.y);   // hand the plane back to its owner lane
+        s_jobid[job][2] = __float_as_uint(fit.z); s_jobid[job][3] = __float_as_uint(fit.w);
+      }
+      __syncthreads();   // also: nobody reads s_pts after this point (its memory is re-used below)
+      if (my_job != ~0u && my_job >= base && my_job < base + kCapJobs) {
+        const uint32_t slot = my_job - base;
+        pl = make_float4(__uint_as_float(s_jobid[slot][0]), __uint_as_float(s_jobid[slot][1]), __uint_as_float(s_jobid[slot][2]), __uint_as_float(s_jobid[slot][3]));
+        if (LIO && kp.lio_ref) { ref_fit = true; ref_ok = s_job[slot] != 0u; }
+      }
+      if (base + kCapJobs >= njobs) break;
+      __syncthreads();   // the slots are free for the next round of the queue
     }
   } else {
     if (live) pl = gload4(d.planes + ((LIO && kp.lio_ref == 2) ? __float_as_uint(p.w) : i));   // plane of the previous ObsModel call (clean semantics: NaN = none)

@@ -519,6 +519,9 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   std::memset(w->h_flags, 0, (size_t)max_rounds * n);
   launch_init_states(st, w->d_states, w->d_guesses, n, g.max_iterations, host_window ? n : window, w->d_queue);
   const bool stats_on = (c0->profiling & 1) != 0;      // HIP events around the residual launches
+  const bool stats_sampled = stats_on && (c0->profiling & 8) != 0;   // ... every 4th launch only; the phase moves from batch to batch
+  const unsigned prof_phase = stats_sampled ? (unsigned)(c0->stats.linearize_launches & 3u) : 0u;
+  uint64_t timed_launches = 0, timed_slots = 0, launched_slots = 0;
   const bool timing_on = (c0->profiling & 4) != 0;     // diagnostic: in-kernel phase stamps (stats.phase_cycles)
   const bool counters_on = (c0->profiling & 2) != 0 || timing_on;   // kNN candidate / probe counters (slower kernel variant)
   if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 16, st));
@@ -542,9 +545,13 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       kpr.use_list = 1;
       std::memcpy(kpr.active, act.data(), act.size());
     }
-    if (stats_on) {
+    const bool timed = stats_on && (!stats_sampled || (((unsigned)r + prof_phase) & 3u) == 0u);
+    launched_slots += (uint64_t)nl;
+    if (timed) {
       while (w->ev_prof.size() < prof_used + 3) { hipEvent_t e; HIPCK(c0, hipEventCreate(&e)); w->ev_prof.push_back(e); }
       HIPCK(c0, hipEventRecord(w->ev_prof[prof_used], st));
+      timed_launches++;
+      timed_slots += (uint64_t)nl;
     }
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
@@ -558,7 +565,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
-    if (stats_on) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
+    if (timed) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
     if (!fuse) launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
     if (is_lm) {
       if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), true);
@@ -566,7 +573,10 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       else launch_trial(st, w->d_descs, w->d_states, kpr, nl);
       launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, true, true, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
     }
-    if (stats_on) { HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st)); prof_used += 3; }
+    if (timed) {
+      if (!stats_sampled) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 2], st));
+      prof_used += 3;
+    }
     rounds_done = r + 1;
     std::vector<uint8_t> this_list = act;   // pairs launched in round r
     if (r >= 1) {  // look one round behind so the GPU always has the next round queued
@@ -578,12 +588,19 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       for (int k = 0; k < np; k++) {
         const int i = use_list ? (int)prev_list[(size_t)k] : k;
         unsigned spins = 0;
+        auto next_query = t_start + std::chrono::milliseconds(5);
         while (row[i] == 0) {   // the round's status byte of pair i has not landed yet
           if ((++spins & 0xfff) == 0) {
             // on both error returns the queued kernels may still be writing into the workspace and h_flags: drain the stream
             // first, so that the caller can destroy the context safely
-            if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(20)) { (void)hipStreamSynchronize(st); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
-            if (hipStreamQuery(st) == hipSuccess && row[i] == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
+            const auto now = std::chrono::steady_clock::now();
+            if (now - t_start > std::chrono::seconds(20)) { (void)hipStreamSynchronize(st); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
+            // the runtime is asked only after a wait far beyond any round (a query takes the locks the other slots' launches
+            // need: polled every few microseconds by several waiting threads it throttled every launch of the process)
+            if (now >= next_query) {
+              next_query = now + std::chrono::milliseconds(5);
+              if (hipStreamQuery(st) == hipSuccess && row[i] == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
+            }
           }
         }
         any_active |= row[i] == 1;
@@ -627,11 +644,14 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     for (size_t k = 0; k + 2 < prof_used + 1; k += 3) {
       float t = 0.f;
       if (hipEventElapsedTime(&t, w->ev_prof[k], w->ev_prof[k + 1]) == hipSuccess) ms += t;
-      if (hipEventElapsedTime(&t, w->ev_prof[k + 1], w->ev_prof[k + 2]) == hipSuccess) ms2 += t;
+      if (!stats_sampled && hipEventElapsedTime(&t, w->ev_prof[k + 1], w->ev_prof[k + 2]) == hipSuccess) ms2 += t;
     }
     c0->stats.linearize_ms += ms;
     c0->stats.residual_ms += ms2;
+    c0->stats.timed_launches += timed_launches;
+    c0->stats.timed_pair_slots += timed_slots;
   }
+  c0->stats.launched_pair_slots += launched_slots;
   c0->stats.linearize_launches += (uint64_t)rounds_done;
   uint64_t passes = 0;
   int worst = PCM_OK;

@@ -90,6 +90,74 @@ def run_pipelined_steps(k: int, n_slots: int, sub_step, gather=None, stagger_s: 
     return last
 
 
+def run_rotating_steps(k: int, n_slots: int, step_fn, gather=None, stagger_s: float = 0.0, on_thread_start=None):
+    """k passes over the rank's WHOLE batch, pass s on pipeline slot ``s % n_slots``; returns the result of the last pass.
+
+    ``step_fn(slot, wait_prev)`` runs one pass on the slot's own registration objects / stream and returns when the slot's result
+    block is complete; it must call ``wait_prev()`` (when not None) before it overwrites the block of the slot's previous pass.
+    ``gather(slot)`` (None on a single rank) performs the collective for that block and returns when it has completed.
+
+    Unlike :func:`run_pipelined_steps` (a fixed subset of the pairs per slot) every slot sees the same mix of fast and slow
+    converging pairs, so no slot is the permanent critical path; the slow tail of pass s runs under the bulk of pass s + 1.
+    Collectives: ONE thread issues them in pass order -- identical on every rank by construction, on ONE communicator.
+    """
+    import threading
+    import time
+    n_slots = max(1, min(n_slots, k))
+    results = [None] * k
+    errs = []
+    done = [threading.Event() for _ in range(k)] if gather else None        # pass s finished its compute
+    gathered = [threading.Event() for _ in range(k)] if gather else None    # ... and its block has been gathered
+
+    def worker(j):
+        try:
+            if on_thread_start:
+                on_thread_start()
+            if stagger_s > 0 and j > 0:
+                time.sleep(j * stagger_s)
+            for s in range(j, k, n_slots):
+                wait_prev = (lambda prev=s - n_slots: gathered[prev].wait()) if (gather and s >= n_slots) else None
+                results[s] = step_fn(j, wait_prev)
+                if s >= n_slots:
+                    results[s - n_slots] = None
+                if gather:
+                    done[s].set()
+        except Exception as e:   # surfaced in the calling thread
+            errs.append(e)
+            if gather:
+                for ev in done:
+                    ev.set()
+
+    def comm_worker():
+        try:
+            if on_thread_start:
+                on_thread_start()
+            for s in range(k):
+                done[s].wait()
+                if errs:
+                    return
+                gather(s % n_slots)
+                gathered[s].set()
+        except Exception as e:
+            errs.append(e)
+        finally:
+            for ev in gathered:
+                ev.set()
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in range(n_slots)] if (n_slots > 1 or gather) else []
+    if gather:
+        ths.append(threading.Thread(target=comm_worker))
+    if not ths:
+        worker(0)
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    if errs:
+        raise errs[0]
+    return results[k - 1]
+
+
 def split_sub_batches(n_local: int, n_slots: int) -> list:
     """Contiguous sub-batches of a rank's pairs (one per pipeline slot / stream)."""
     n_slots = max(1, min(n_slots, n_local))

@@ -122,6 +122,81 @@ def test_pipelined_steps_with_uneven_ranks_gloo(world, slots):
             assert steps_seen == [n // nslots] * world
 
 
+def _rotating_worker(rank, world, port, pairs_per_rank, slots, steps, q):
+    """bench.py's default N>1 control flow (sharding.run_rotating_steps: pass s of the whole batch on slot s % slots) with random
+    per-rank delays in place of the GPU work: the ranks finish their passes in different orders, a slot overwrites its result
+    block only after that block's gather, and every collective must pair up blocks of the same pass."""
+    import random
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pointcloud_slam_amd as pcm
+    sh = pcm.sharding
+    ids = sh.pair_ids_for_rank(pairs_per_rank, rank)
+    S = min(slots, steps)
+    rec = sh.RECORD_BYTES
+    results = torch.zeros(S, pairs_per_rank * rec, dtype=torch.uint8)      # one result block per slot
+    gathered = torch.zeros(S, world, pairs_per_rank * rec, dtype=torch.uint8)
+    rng = random.Random(1000 * rank + 29)
+    pass_of = [j - S for j in range(S)]      # the pass whose results slot j holds
+    log = []
+
+    def step_fn(j, wait_prev):
+        time.sleep(rng.uniform(0.0, 0.03) * (1 + (rank + j) % 3))
+        if wait_prev is not None:
+            wait_prev()
+        pass_of[j] += S
+        res = []
+        for i in range(pairs_per_rank):
+            T = np.eye(4); T[:3, 3] = [ids[i], rank, pass_of[j]]
+            res.append({"T64": T, "iterations": pass_of[j], "converged": 1, "num_inliers": 1000 + ids[i]})
+        results[j] = torch.from_numpy(sh.pack_results(res))
+        return pass_of[j]
+
+    def gather(j):
+        got = sh.gather_records(results[j].clone(), world)
+        gathered[j] = got
+        rows = [sh.records_to_results(got[r].numpy()) for r in range(world)]
+        log.append((j, [row[0]["iterations"] for row in rows]))
+
+    last = sh.run_rotating_steps(steps, slots, step_fn, gather, stagger_s=0.01 * (rank % 2))
+    assert last == steps - 1
+    jl = (steps - 1) % S
+    out = [sh.records_to_results(gathered[jl, r].numpy()) for r in range(world)]
+    summary = [[(round(float(x["T64"][0, 3])), round(float(x["T64"][2, 3])), x["num_inliers"]) for x in row] for row in out]
+    q.put((rank, summary, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,slots,steps", [(2, 2, 7), (3, 3, 5), (4, 2, 6), (2, 4, 3)])
+def test_rotating_steps_with_uneven_ranks_gloo(world, slots, steps):
+    ppr = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rotating_worker, args=(r, world, port, ppr, slots, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, summary, log = q.get(timeout=180)
+        got[rank] = (summary, log)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    S = min(slots, steps)
+    want = [[(r * ppr + i, steps - 1, 1000 + r * ppr + i) for i in range(ppr)] for r in range(world)]   # the last pass, every rank's block
+    for rank in range(world):
+        summary, log = got[rank]
+        assert summary == want
+        assert [j for j, _ in log] == [s % S for s in range(steps)]            # collectives in pass order ...
+        for s, (_, passes_seen) in enumerate(log):
+            assert passes_seen == [s] * world                                  # ... each pairing blocks of the same pass on all ranks
+
+
 @pytest.mark.parametrize("slots", [1, 2])
 def test_gather_of_sharded_results_gloo(slots):
     world, ppr = 2, 5

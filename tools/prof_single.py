@@ -10,6 +10,7 @@ ap.add_argument("--scan", type=int, default=100000)
 ap.add_argument("--map", type=int, default=1000000)
 ap.add_argument("--flags", type=int, default=0)
 ap.add_argument("--cache", default="")
+ap.add_argument("--lib", default="", help="A/B: load this build of the library instead of the in-tree one")
 ap.add_argument("--phases", type=int, default=1)
 a = ap.parse_args()
 if a.cache:
@@ -21,6 +22,8 @@ else:
     ps = [synth.make_pair(i, a.scan, a.map) for i in range(a.pairs)]
     scans = [p.scan for p in ps]; maps = [p.submap for p in ps]; guesses = [p.guess for p in ps]
 import pointcloud_slam_amd as pcm
+if a.lib:
+    pcm.capi.library_path = lambda: os.path.abspath(a.lib)
 regs = []
 for s, m in zip(scans, maps):
     r = pcm.P2PlaneRegistration(0, optimizer="GN", voxel_resolution=0.5, num_neighbors=27, flags=a.flags)
