@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--sort-source", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--pairs-cache", default="", help="load the rank-0 pairs from an .npz written by tools/gen_cache.py (profiling runs: the program behind "
+                    "rocprofv3 must not fork, and generating 64 pairs in-process takes minutes)")
     ap.add_argument("--slot-priority", type=int, default=0, help="1: the pipeline slots run on streams of descending priority (slot 0 highest), so the "
                     "tail rounds of one slot are not queued behind the bulk of another")
     ap.add_argument("--stagger", type=float, default=0.5, help="start offset between the pipeline slots, in units of one warm pass")
@@ -144,7 +146,13 @@ def main():
     workers = args.gen_workers or max(1, min(ncpu // max(1, min(world, 8)), 16))
     ids = [rank * args.pairs_per_gpu + i for i in range(args.pairs_per_gpu)]   # = sharding.pair_ids_for_rank (kept import-free: runs before the GPU is touched)
     t0 = time.perf_counter()
-    pairs = generate_pairs(ids, args.scan_points, args.map_points, workers)
+    if args.pairs_cache and world == 1:
+        z = np.load(args.pairs_cache)
+        if int(z["n"]) < len(ids):
+            raise SystemExit("--pairs-cache holds %d pairs, %d needed" % (int(z["n"]), len(ids)))
+        pairs = [(z["scan%d" % i], z["map%d" % i], z["guess%d" % i], z["gt%d" % i]) for i in ids]
+    else:
+        pairs = generate_pairs(ids, args.scan_points, args.map_points, workers)
     t_gen = time.perf_counter() - t0
 
     import torch

@@ -281,22 +281,30 @@ __global__ void __launch_bounds__(256) k_finish_round(const PairDesc* __restrict
     const uint32_t per = (uint32_t)(trial_round ? kp.points_per_block : kp.lin_points_per_block);
     const int nblocks = (int)((d.src.num_points + per - 1u) / per);
     const int j = threadIdx.x & 31, g8 = threadIdx.x >> 5;
-    double v[4];
-    // canonical partition: group r (0..31) = rows r, r + 32, r + 64, ...; thread (g8, j) sums groups r = g8 + 8q, q = 0..3
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    // canonical partition: group r (0..31) = rows r, r + 32, r + 64, ...; thread (g8, j) sums groups r = g8 + 8q, q = 0..3, each in
+    // row order.  The four groups advance together, 16 independent loads in flight per trip (a 100k-point scan has 391 rows: 4
+    // trips to memory instead of 16); a row past the end is skipped, not added as zero (-0.0 + 0.0 would lose the sign)
+    if (j < kNumSums) {
+      for (int b0 = 0; b0 < nblocks; b0 += 128) {
+        double x[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = g8 + 8 * q;
-      double acc = 0.0;
-      if (j < kNumSums) {
-        int b = r;
-        for (; b + 96 < nblocks; b += 128) {   // 4 independent loads in flight
-          const double v0 = gload_d(d.partials + (size_t)b * kPartialStride + j), v1 = gload_d(d.partials + (size_t)(b + 32) * kPartialStride + j),
-                       v2 = gload_d(d.partials + (size_t)(b + 64) * kPartialStride + j), v3 = gload_d(d.partials + (size_t)(b + 96) * kPartialStride + j);
-          acc = (((acc + v0) + v1) + v2) + v3;
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int b = b0 + g8 + 8 * q + 32 * k;
+            x[q][k] = b < nblocks ? gload_d(d.partials + (size_t)b * kPartialStride + j) : 0.0;
+          }
         }
-        for (; b < nblocks; b += 32) acc += gload_d(d.partials + (size_t)b * kPartialStride + j);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int b = b0 + g8 + 8 * q + 32 * k;
+            if (b < nblocks) v[q] += x[q][k];
+          }
+        }
       }
-      v[q] = acc;
     }
     // group totals added in group order, 16 groups at a time through 4 KB of LDS
     double t = 0.0;
@@ -398,11 +406,13 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
   unsigned long long t_prev = 0;
   if (TIMING) t_prev = __builtin_amdgcn_s_memtime();
   float4 p = make_float4(0.f, 0.f, 0.f, 1.f);
+  float pn_body = 0.f;
   float q[3] = {0.f, 0.f, 0.f};
   int cx = 0, cy = 0, cz = 0;
   bool search = false;  // lanes whose query voxel lies inside the key range of the table
   if (live) {
     p = gload4(d.src.pts + i);
+    pn_body = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);   // p_body.norm() of the 81 pd2^2 test (:631), kept instead of the point
     if (LIO) {   // p_w = R_wl * p_body + t_wl with R_wl a float quaternion (Eigen _transformVector)  laser_mapping.cc:602-612
       const float qx = d.lio.q_wl[0], qy = d.lio.q_wl[1], qz = d.lio.q_wl[2], qw = d.lio.q_wl[3];
       float uv[3] = {qy * p.z - qz * p.y, qz * p.x - qx * p.z, qx * p.y - qy * p.x};
@@ -703,7 +713,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
           }
           if (sel) {
             const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
-            const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+            const float pn = pn_body;
             if (pn > 81.f * pd2 * pd2) res = pd2;
           }
           aux[0] = res;
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
           if (do_search) gstore4(d.planes + i, pl);                        // plane_coef_[i]; the residual test is re-evaluated every call
           if (sel) {
             res = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
-            const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+            const float pn = pn_body;
             sel = pn > 81.f * res * res;
           }
         }
@@ -785,7 +795,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
         bool sel = !(pl.x != pl.x);
         if (sel) {
           const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
-          const float pn = pcm_sqrtf_rn(p.x * p.x + p.y * p.y + p.z * p.z);
+          const float pn = pn_body;
           sel = pn > 81.f * pd2 * pd2;                                       // :631
           if (sel) {
             // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]

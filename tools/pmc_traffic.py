@@ -11,7 +11,7 @@ figure is an upper estimate of the read side."""
 import csv, glob, json, sys, collections
 
 def load(d, counter):
-    f = sorted(glob.glob(d + '/*/*counter_collection.csv'))[-1]
+    f = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True))[-1]
     tot = 0.0; disp = set()
     for r in csv.DictReader(open(f)):
         if 'k_linearize<false, false' not in r['Kernel_Name'] or r['Counter_Name'] != counter:
