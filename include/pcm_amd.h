@@ -101,7 +101,9 @@ typedef struct pcm_config {
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
   int32_t batch_window;          /* pcm_align_batch: pairs iterating at a time; finished pairs hand their slot to queued ones (0 = all at once; speed only) */
   int32_t voxel_mode;            /* VGICP VoxelAccumulationMode (gicp_settings.hpp:10): 0 ADDITIVE (default), 1 ADDITIVE_WEIGHTED, 2 MULTIPLICATIVE */
-  int32_t reserved[1];
+  float neighbor_search_radius;  /* NDT_P2D / NDT_D2D / VGICP_CUDA: > 0 selects NeighborSearchMethod::DIRECT_RADIUS -- every voxel offset with
+                                  * |offset| <= radius + 1e-3, radius in voxels (cuda/ndt_cuda.cu:70-83, cuda/fast_vgicp_cuda.cu:77-90;
+                                  * setNeighborSearchMethod(method, radius)); num_neighbors is not read then.  0 (default): off */
 } pcm_config;
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */

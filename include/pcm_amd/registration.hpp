@@ -170,7 +170,7 @@ public:
 
 // fast_gicp::FastGICP (gicp/fast_gicp.hpp:24-95): setCorrespondenceRandomness, setRegularizationMethod, covariances
 enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };   // gicp_settings.hpp
-enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1 };                               // gicp_settings.hpp
+enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1, /* VGICP_CUDA / NDTCuda only */ DIRECT_RADIUS };   // gicp_settings.hpp:8
 enum class VoxelAccumulationMode { ADDITIVE, ADDITIVE_WEIGHTED, MULTIPLICATIVE };              // gicp_settings.hpp
 
 template <typename PointSource, typename PointTarget>
@@ -210,6 +210,30 @@ public:
   void setVoxelAccumulationMode(VoxelAccumulationMode m) { this->cfg_.voxel_mode = static_cast<int>(m); }   // fast_vgicp_impl.hpp:38-40
 };
 
+namespace detail {
+// setNeighborSearchMethod(method, radius) of the CUDA-core classes (ndt_cuda_impl.hpp:30-32, fast_vgicp_cuda_impl.hpp:59-61):
+// DIRECT_RADIUS takes the radius in voxels (ndt_cuda.cu:70-83); the other methods ignore it
+inline void set_search_method(pcm_config& cfg, NeighborSearchMethod m, double radius) {
+  cfg.neighbor_search_radius = 0.f;
+  if (m == NeighborSearchMethod::DIRECT_RADIUS) cfg.neighbor_search_radius = static_cast<float>(radius);
+  else cfg.num_neighbors = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1);
+}
+}  // namespace detail
+
+// fast_gicp::FastVGICPCuda (gicp/fast_vgicp_cuda.hpp; impl/fast_vgicp_cuda_impl.hpp:21-31): the float CUDA core -- 20-NN covariances,
+// PLANE, resolution 1.0, DIRECT1 (cuda/fast_vgicp_cuda.cu:26-34)
+template <typename PointSource, typename PointTarget>
+class VgicpCudaRegistration : public GicpRegistration<PointSource, PointTarget> {
+public:
+  explicit VgicpCudaRegistration(int device = 0) : GicpRegistration<PointSource, PointTarget>(device, PCM_MODEL_VGICP_CUDA) {
+    this->reg_name_ = "pcm_amd::VgicpCudaRegistration";
+    this->cfg_.voxel_resolution = 1.0f;
+    this->cfg_.num_neighbors = 1;
+  }
+  void setCorrespondenceRandomness(int) {}                                                       // a no-op there too (fast_vgicp_cuda_impl.hpp:37-38)
+  void setNeighborSearchMethod(NeighborSearchMethod m, double radius = -1.0) { detail::set_search_method(this->cfg_, m, radius); }
+};
+
 // fast_gicp::NDTCuda (ndt/ndt_cuda.hpp:21-71): D2D, DIRECT7, resolution 1.0  (cuda/ndt_cuda.cu:15-22)
 enum class NDTDistanceMode { P2D, D2D };
 template <typename PointSource, typename PointTarget>
@@ -221,7 +245,7 @@ public:
     this->cfg_.num_neighbors = 7;
   }
   void setDistanceMode(NDTDistanceMode m) { this->cfg_.model = m == NDTDistanceMode::P2D ? PCM_MODEL_NDT_P2D : PCM_MODEL_NDT_D2D; }
-  void setNeighborSearchMethod(NeighborSearchMethod m, double /*radius*/ = -1.0) { this->cfg_.num_neighbors = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1); }
+  void setNeighborSearchMethod(NeighborSearchMethod m, double radius = -1.0) { detail::set_search_method(this->cfg_, m, radius); }
 };
 
 // pclomp::NormalDistributionsTransform (ndt_omp/include/pclomp/ndt_omp.h:77-310): the operator jueying_slam's

@@ -62,6 +62,8 @@ def lib():
         L.orc_num_inliers.argtypes = [C.c_void_p]
         L.orc_get_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
         L.orc_obs_model.argtypes = [C.c_void_p, C.POINTER(LioState), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.orc_set_neighbor_radius.argtypes = [C.c_void_p, C.c_double]
+        L.orc_set_neighbor_radius.restype = None
         L.orc_set_lio_reference_semantics.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_lio_reference_semantics.restype = None
         L.orc_get_lio_members.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
@@ -168,6 +170,10 @@ class Oracle:
         HTH = np.zeros((12, 12)); HTh = np.zeros(12); n = C.c_int(); s2 = C.c_double()
         lib().orc_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), HTH.ctypes.data, HTh.ctypes.data, C.byref(n), C.byref(s2))
         return HTH, HTh, n.value, s2.value
+
+    def set_neighbor_radius(self, radius):
+        """NeighborSearchMethod::DIRECT_RADIUS of the CUDA-core models (radius in voxels; 0 = off)."""
+        lib().orc_set_neighbor_radius(self._h, float(radius))
 
     def set_lio_reference_semantics(self, on=True):
         """Keep residuals_/point_selected_surf_/plane_coef_ across calls and frames as LaserMapping's members do."""

@@ -49,6 +49,7 @@ typedef struct oracle {
   long nn_cap;
   /* LaserMapping members that outlive one ObsModel call and one frame (laser_mapping.cc:335-339): kept only
    * in the reference-semantics mode of orc_obs_model */
+  double nb_radius;            /* > 0: NeighborSearchMethod::DIRECT_RADIUS (orc_set_neighbor_radius) */
   int lio_ref;                 /* orc_set_lio_reference_semantics */
   float *ref_plane;            /* plane_coef_           [ref_n][4] */
   float *ref_resid;            /* residuals_            [ref_n]    */

@@ -55,7 +55,20 @@ typedef struct orc_gauss_state {
 
 static const int ORC_DIRECT7[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
 
-static void offsets_for(int n, int out[27][3]) {
+#define ORC_MAX_OFFSETS 343   /* DIRECT_RADIUS up to radius 3 */
+
+/* NeighborSearchMethod::DIRECT_RADIUS  ndt_cuda.cu:70-83: i, j, k loops over [-range, range], kept when |offset| <= radius + 1e-3 */
+static int offsets_radius(double radius, int out[ORC_MAX_OFFSETS][3]) {
+  const int range = (int)ceil(radius);
+  int t = 0;
+  for (int i = -range; i <= range; i++)
+    for (int j = -range; j <= range; j++)
+      for (int k = -range; k <= range; k++)
+        if (sqrt((double)(i * i + j * j + k * k)) <= radius + 1e-3 && t < ORC_MAX_OFFSETS) { out[t][0] = i; out[t][1] = j; out[t][2] = k; t++; }
+  return t;
+}
+
+static void offsets_for(int n, int out[ORC_MAX_OFFSETS][3]) {
   if (n == 27) {
     int t = 0;
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) { out[t][0] = i - 1; out[t][1] = j - 1; out[t][2] = k - 1; t++; }
@@ -224,9 +237,10 @@ static double ndt_pass(oracle *o, const double T[16], int update, double *H, dou
   orc_gauss_prepare(o);
   const int d2d = o->cfg.model == ORC_MODEL_NDT_D2D;
   const int vgc = o->cfg.model == ORC_MODEL_VGICP_CUDA;   /* compute_derivatives.cu:49-92: the D2D form with per-point cov_A, w = sqrt(n), no Cauchy weight */
-  const int nO = o->cfg.num_neighbors == 27 ? 27 : (o->cfg.num_neighbors == 1 ? 1 : 7);
-  int offs[27][3];
-  offsets_for(nO, offs);
+  int nO = o->cfg.num_neighbors == 27 ? 27 : (o->cfg.num_neighbors == 1 ? 1 : 7);
+  int offs[ORC_MAX_OFFSETS][3];
+  if (o->nb_radius > 0.0) nO = offsets_radius(o->nb_radius, offs);
+  else offsets_for(nO, offs);
   const float res = (float)o->cfg.voxel_resolution;
   float R[9], t[3];
   for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i * 3 + j] = (float)T[i * 4 + j]; t[i] = (float)T[i * 4 + 3]; }

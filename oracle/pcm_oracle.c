@@ -456,6 +456,11 @@ static void lio_ref_resize(oracle *o, long n) {
   o->ref_n = n;
 }
 
+void orc_set_neighbor_radius(void *h, double radius) {
+  oracle *o = (oracle *)h;
+  o->nb_radius = radius > 0.0 ? radius : 0.0;
+}
+
 void orc_set_lio_reference_semantics(void *h, int on) {
   oracle *o = (oracle *)h;
   o->lio_ref = on != 0;

@@ -43,7 +43,7 @@ class PcmConfig(C.Structure):
                 ("max_corr_dist", C.c_float), ("k_correspondences", C.c_int32),
                 ("regularization", C.c_int32), ("sort_source", C.c_int32), ("flags", C.c_int32),
                 ("map_capacity", C.c_int32), ("ndt_step_size", C.c_float), ("ndt_outlier_ratio", C.c_float),
-                ("batch_window", C.c_int32), ("voxel_mode", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("batch_window", C.c_int32), ("voxel_mode", C.c_int32), ("neighbor_search_radius", C.c_float)]
 
 
 class PcmResult(C.Structure):

@@ -25,6 +25,13 @@ namespace pcm {
 // neighbour offsets in the reference's order (ndt_cuda.cu:35-88)
 __constant__ int8_t c_direct7[7][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {-1, 0, 0, 0}, {0, 1, 0, 0}, {0, -1, 0, 0}, {0, 0, 1, 0}, {0, 0, -1, 0}};
 
+// DIRECT_RADIUS: entry k of the cube [-range, range]^3 (i, j, k loops); false when the reference's list does not hold it
+__device__ inline bool ndt_offset_radius(int range, double radius, int k, int& ox, int& oy, int& oz) {
+  const int D = 2 * range + 1;
+  ox = k / (D * D) - range; oy = (k / D) % D - range; oz = k % D - range;
+  return sqrt((double)(ox * ox + oy * oy + oz * oz)) <= radius + 1e-3;   // offset.cast<double>().norm() <= radius + 1e-3
+}
+
 __device__ inline void ndt_offset(int nO, int k, int& ox, int& oy, int& oz) {
   if (nO == 27) { ox = k / 9 - 1; oy = (k / 3) % 3 - 1; oz = k % 3 - 1; }   // i, j, k loops of DIRECT27
   else { ox = c_direct7[k][0]; oy = c_direct7[k][1]; oz = c_direct7[k][2]; }
@@ -89,7 +96,7 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
   uint32_t end = begin + per;
   end = end < d.src.num_points ? end : d.src.num_points;
   const TargetView tg = d.tgt;
-  const int nO = kp.num_neighbors;
+  const int nO = kp.nb_range > 0 ? (2 * kp.nb_range + 1) * (2 * kp.nb_range + 1) * (2 * kp.nb_range + 1) : kp.num_neighbors;
   const double* T = TRIAL ? states[pair].xi : states[pair].x0;
   float R[9], t[3], Re[9];
 #pragma unroll
@@ -155,8 +162,10 @@ __global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs,
         v = *(const PCM_GLOBAL int32_t*)(d.corr + (size_t)i * nO + k);
       } else {
         int ox, oy, oz;
-        ndt_offset(nO, k, ox, oy, oz);
-        v = inrange ? voxel_lookup(tg, cx + ox, cy + oy, cz + oz, cbx, cby, cbz, slot, vox_base) : -1;
+        bool listed = true;
+        if (kp.nb_range > 0) listed = ndt_offset_radius(kp.nb_range, kp.nb_radius, k, ox, oy, oz);
+        else ndt_offset(nO, k, ox, oy, oz);
+        v = (inrange && listed) ? voxel_lookup(tg, cx + ox, cy + oy, cz + oz, cbx, cby, cbz, slot, vox_base) : -1;
         *(PCM_GLOBAL int32_t*)(d.corr + (size_t)i * nO + k) = v;
       }
       if (v < 0) continue;

@@ -126,6 +126,15 @@ size_t num_elements(const pcm_ctx* c) { return c->cfg.model == PCM_MODEL_NDT_D2D
 
 bool is_ndt(int model) { return model == PCM_MODEL_NDT_P2D || model == PCM_MODEL_NDT_D2D; }
 bool is_gicp(int model) { return model == PCM_MODEL_GICP || model == PCM_MODEL_VGICP || model == PCM_MODEL_VGICP_CUDA; }   // models with per-point covariances
+bool radius_model(int model) { return is_ndt(model) || model == PCM_MODEL_VGICP_CUDA; }
+// offsets examined per element: DIRECT_RADIUS walks the cube around the voxel (the list is its subset), else the table
+size_t neighbor_slots(const pcm_config& g) {
+  if (radius_model(g.model) && g.neighbor_search_radius > 0.f) {
+    const size_t D = 2 * (size_t)std::ceil((double)g.neighbor_search_radius) + 1;
+    return D * D * D;
+  }
+  return (size_t)g.num_neighbors;
+}
 int ndt_kind(int model) { return model == PCM_MODEL_NDT_D2D ? 1 : (model == PCM_MODEL_VGICP_CUDA ? 2 : 0); }
 
 int validate_config(pcm_ctx* c, const pcm_config& g) {
@@ -142,6 +151,10 @@ int validate_config(pcm_ctx* c, const pcm_config& g) {
     if (g.regularization < PCM_REG_NONE || g.regularization > PCM_REG_PCLOMP || (g.regularization == PCM_REG_PCLOMP && g.model == PCM_MODEL_VGICP_CUDA)) { c->err = "bad regularization method"; return PCM_ERR_INVALID_ARGUMENT; }
     if (!(g.max_corr_dist > 0.f)) { c->err = "max_corr_dist must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
     if (g.voxel_mode < 0 || g.voxel_mode > 2) { c->err = "voxel_mode must be 0 (ADDITIVE), 1 (ADDITIVE_WEIGHTED) or 2 (MULTIPLICATIVE)"; return PCM_ERR_INVALID_ARGUMENT; }
+  }
+  if (g.neighbor_search_radius != 0.f) {   // NeighborSearchMethod::DIRECT_RADIUS: "supported on only VGICP_CUDA" (gicp_settings.hpp:8) and NDTCuda
+    if (!radius_model(g.model)) { c->err = "neighbor_search_radius (DIRECT_RADIUS) is a mode of NDT_P2D / NDT_D2D / VGICP_CUDA"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (!(g.neighbor_search_radius > 0.f) || g.neighbor_search_radius > 3.f) { c->err = "neighbor_search_radius must be in (0, 3] voxels"; return PCM_ERR_INVALID_ARGUMENT; }
   }
   if (g.optimizer != PCM_OPT_GAUSS_NEWTON && g.optimizer != PCM_OPT_LEVENBERG_MARQUARDT) { c->err = "bad optimizer"; return PCM_ERR_INVALID_ARGUMENT; }
   if (!(g.voxel_resolution > 0.f)) { c->err = "voxel_resolution must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
@@ -302,7 +315,7 @@ int prepare(pcm_ctx* c) {
     if (rc != PCM_OK) return rc;
   }
   if (gauss || gicp) {
-    const size_t need = num_elements(c) * (size_t)(c->cfg.model == PCM_MODEL_GICP ? 1 : c->cfg.num_neighbors);
+    const size_t need = num_elements(c) * (c->cfg.model == PCM_MODEL_GICP ? (size_t)1 : neighbor_slots(c->cfg));
     if (c->corr_cap < need) {
       if (c->corr) hipFree(c->corr);
       c->corr = nullptr; c->corr_cap = 0;
@@ -385,6 +398,10 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
 KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   KernelParams kp{};
   kp.num_neighbors = g.num_neighbors;
+  if (radius_model(g.model) && g.neighbor_search_radius > 0.f) {
+    kp.nb_range = (int32_t)std::ceil((double)g.neighbor_search_radius);
+    kp.nb_radius = (double)g.neighbor_search_radius;
+  }
   kp.knn = g.knn;
   kp.min_knn = g.min_knn;
   {  // d2 < fl  <=>  double(d2) < max_range^2  when fl is the smallest float >= max_range^2
@@ -419,7 +436,7 @@ LsqParams lsq_params(const pcm_config& g) {
 bool same_solver_config(const pcm_config& a, const pcm_config& b) {
   return a.model == b.model && a.optimizer == b.optimizer && a.max_iterations == b.max_iterations && a.lm_max_iterations == b.lm_max_iterations &&
          a.rotation_eps == b.rotation_eps && a.translation_eps == b.translation_eps && a.lm_init_lambda_factor == b.lm_init_lambda_factor &&
-         a.num_neighbors == b.num_neighbors && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold && a.flags == b.flags &&
+         a.num_neighbors == b.num_neighbors && a.neighbor_search_radius == b.neighbor_search_radius && a.max_range == b.max_range && a.plane_threshold == b.plane_threshold && a.flags == b.flags &&
          (a.model == PCM_MODEL_P2PLANE || a.voxel_resolution == b.voxel_resolution) && (!is_gicp(a.model) || a.max_corr_dist == b.max_corr_dist);
 }
 

@@ -228,6 +228,8 @@ struct KernelParams {
   int32_t do_step;            // 1: k_finish_round runs the GN/LM step; 0: it exports the sums (parity hooks)
   int32_t lio_rematch;        // LIO: ekfom_data.converge (1: search + plane fit, 0: re-use the stored planes)
   int32_t lio_extrinsic;      // LIO: extrinsic_est_en (columns 6..11 of h_x)
+  int32_t nb_range;           // NDT / VGICP_CUDA DIRECT_RADIUS: ceil(radius) (0: the DIRECT1 / 7 / 27 tables); the offsets are the cube
+  double nb_radius;           //   [-range, range]^3 in i, j, k order, those with |offset| > radius + 1e-3 skipped (ndt_cuda.cu:70-83)
   int32_t lio_ref;            // LIO: 0 clean semantics; reference semantics with the per-point members indexed by the tile position (1) or by
                               //      the scan position kept in the point's w (2: the scan was re-ordered on device)
   int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)

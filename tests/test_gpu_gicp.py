@@ -158,6 +158,22 @@ def test_cuda_linearize_matches_oracle(pcm, pair, kw):
         assert abs(g.compute_error(T2) - e0) <= 1e-4 * abs(e0)
 
 
+@pytest.mark.parametrize("radius", [1.5, 2.0])
+def test_cuda_direct_radius_matches_oracle(pcm, pair, radius):
+    """NeighborSearchMethod::DIRECT_RADIUS, "supported on only VGICP_CUDA" (gicp_settings.hpp:8; cuda/fast_vgicp_cuda.cu:77-90)."""
+    p = pair
+    o, g = _both_cuda(pcm, "LM", p, neighbor_search_radius=radius)
+    o.set_neighbor_radius(radius)
+    for T in (p.guess.astype(np.float64), p.T_gt):
+        c0, H0, b0 = o.linearize(T)
+        c1, H1, b1, inl = g.evaluate_cost(T)
+        assert inl == o.num_inliers and inl > 0
+        assert rel_err(H1, H0) < 1e-4 and rel_err(b1, b0) < 1e-4 and abs(c1 - c0) <= 1e-4 * abs(c0)
+    o7, _ = _both_cuda(pcm, "LM", p, num_neighbors=7)
+    o7.linearize(p.T_gt)
+    assert inl > o7.num_inliers          # a wider neighbourhood than DIRECT7 really was searched
+
+
 @pytest.mark.parametrize("optimizer,kw", [("LM", {}), ("GN", {"num_neighbors": 7}), ("LM", {"num_neighbors": 27})])
 def test_cuda_align_matches_oracle(pcm, pair, optimizer, kw):
     """The DIRECT-voxel objective is discontinuous (a point changes voxel) and on this sparse pair the iteration does not

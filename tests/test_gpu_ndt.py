@@ -48,6 +48,43 @@ def test_ndt_align_matches_oracle(pcm, pair_dense, model, nn, optimizer):
     assert rg.num_linearize == ro.num_linearize and rg.num_compute_error == ro.num_compute_error
 
 
+@pytest.mark.parametrize("model", ["NDT_P2D", "NDT_D2D"])
+@pytest.mark.parametrize("radius,count", [(1.0, 7), (1.5, 19), (2.0, 33)])
+def test_ndt_direct_radius_matches_oracle(pcm, pair_dense, model, radius, count):
+    """NeighborSearchMethod::DIRECT_RADIUS (ndt_cuda.cu:70-83): every voxel offset with |offset| <= radius + 1e-3, radius in
+    voxels -- 7, 19 and 33 offsets for radius 1, 1.5 and 2."""
+    from oracle.loader import result_T
+    p = pair_dense
+    rng = range(-int(np.ceil(radius)), int(np.ceil(radius)) + 1)
+    assert sum(1 for i in rng for j in rng for k in rng if np.sqrt(i * i + j * j + k * k) <= radius + 1e-3) == count
+    o, _ = _both(pcm, model, 7, "LM", p, res=0.5)
+    o.set_neighbor_radius(radius)
+    g = pcm.NdtRegistration(0, model=model, optimizer="LM", voxel_resolution=0.5, neighbor_search_radius=radius)
+    g.set_input_target(p.submap); g.set_input_source(p.scan)
+    T = p.guess.astype(np.float64)
+    c0, H0, b0 = o.linearize(T)
+    c1, H1, b1, inl = g.evaluate_cost(T)
+    assert inl == o.num_inliers and inl > 0
+    assert rel_err(H1, H0) < HB_RTOL and rel_err(b1, b0) < HB_RTOL and abs(c1 - c0) <= HB_RTOL * abs(c0)
+    T2 = T.copy(); T2[:3, 3] += [0.02, -0.01, 0.01]
+    assert abs(g.compute_error(T2) - o.compute_error(T2)) <= HB_RTOL * abs(o.compute_error(T2))
+    if radius == 1.0:   # the same seven offsets as DIRECT7, in another order: the same correspondences
+        o7, _ = _both(pcm, model, 7, "LM", p, res=0.5)
+        o7.linearize(T)
+        assert o7.num_inliers == inl
+    ro, rg = o.align(p.guess), g.align(p.guess)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+    assert rg.iterations == ro.iterations and rg.num_linearize == ro.num_linearize and rg.num_compute_error == ro.num_compute_error
+
+
+def test_direct_radius_is_refused_where_the_reference_has_none(pcm):
+    with pytest.raises(pcm.PcmError):
+        pcm.P2PlaneRegistration(0, neighbor_search_radius=1.5)      # "supported on only VGICP_CUDA" (+ NDTCuda)
+    with pytest.raises(pcm.PcmError):
+        pcm.NdtRegistration(0, neighbor_search_radius=4.0)           # the cube walked per element is capped at radius 3
+
+
 def test_ndt_batch_and_swap(pcm, synth):
     pairs = [synth.make_pair(20 + i, 3000 + 1000 * i, 30000 + 8000 * i, density=60.0) for i in range(3)]
     regs = []
