@@ -26,8 +26,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PCM_LA __host__ __device__ inline
+#define PCM_UNROLL _Pragma("unroll")
 #else
 #define PCM_LA inline
+#define PCM_UNROLL
 #endif
 
 namespace pcm {
@@ -109,7 +111,10 @@ PCM_LA void jacobi_svd(const double* A, double* Uo, double* So, double* Vo) {
   bool finished = false;
   while (!finished) {
     finished = true;
+    // (all trip counts are compile-time: unrolled, the three matrices stay in registers in device code)
+PCM_UNROLL
     for (int p = 1; p < N; p++) {
+PCM_UNROLL
       for (int q = 0; q < p; q++) {
         double thr = precision * maxDiag;
         if (considerAsZero > thr) thr = considerAsZero;
@@ -127,10 +132,18 @@ PCM_LA void jacobi_svd(const double* A, double* Uo, double* So, double* Vo) {
           make_jacobi(m00, m01, m11, jrc, jrs);
           const double tc = jrc, ts = -jrs;                       // j_right.transpose()
           const double jlc = r1c * tc - r1s * ts, jls = r1c * ts + r1s * tc;   // rot1 * j_right^T  (Jacobi.h:49-55)
+PCM_UNROLL
           for (int j = 0; j < N; j++) plane_rot(w[p][j], w[q][j], jlc, jls);
-          if (WANT_U) for (int i = 0; i < N; i++) plane_rot(U[i][p], U[i][q], jlc, jls);
+          if (WANT_U) {
+PCM_UNROLL
+            for (int i = 0; i < N; i++) plane_rot(U[i][p], U[i][q], jlc, jls);
+          }
+PCM_UNROLL
           for (int i = 0; i < N; i++) plane_rot(w[i][p], w[i][q], jrc, -jrs);
-          if (WANT_V) for (int i = 0; i < N; i++) plane_rot(V[i][p], V[i][q], jrc, -jrs);
+          if (WANT_V) {
+PCM_UNROLL
+            for (int i = 0; i < N; i++) plane_rot(V[i][p], V[i][q], jrc, -jrs);
+          }
           const double mx = fabs(w[p][p]) > fabs(w[q][q]) ? fabs(w[p][p]) : fabs(w[q][q]);
           if (mx > maxDiag) maxDiag = mx;
         }

@@ -20,6 +20,7 @@
 #include "pcm_device.h"
 #include "pcm_host.h"
 #include "dev_linalg.h"
+#include "pclndt_host.h"
 
 namespace pcm {
 
@@ -175,8 +176,8 @@ __device__ inline void block_reduce_store(double (&acc)[NS], double* dst) {
 // grid = blocks, block = 256, `per` points per workgroup
 // ---------------------------------------------------------------------------
 template <bool HESS>
-__global__ void __launch_bounds__(256) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
-                                                            double* __restrict__ partials) {
+__device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, const NdtOmpParams& P,
+                                               double* __restrict__ partials) {
   const uint32_t begin = blockIdx.x * per;
   uint32_t end = begin + per;
   end = end < n ? end : n;
@@ -273,8 +274,8 @@ __global__ void __launch_bounds__(256) k_pclndt_derivatives(TargetView tg, const
 // ---------------------------------------------------------------------------
 // k_pclndt_hessian: computeHessian / updateHessian in double  :498-590
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
-                                                        double* __restrict__ partials) {
+__device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, const NdtOmpParams& P,
+                                           double* __restrict__ partials) {
   const uint32_t begin = blockIdx.x * per;
   uint32_t end = begin + per;
   end = end < n ? end : n;
@@ -341,6 +342,178 @@ __global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const Pcl
     }
   }
   block_reduce_store<36>(acc, partials + (size_t)blockIdx.x * kNdtStride);
+}
+
+// one object, the parameters in the kernel arguments (pcm_ndt_derivatives, the host-driven solver)
+template <bool HESS>
+__global__ void __launch_bounds__(256) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+                                                            double* __restrict__ partials) {
+  pclndt_derivatives_body<HESS>(tg, leaves, src, n, per, P, partials);
+}
+__global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+                                                        double* __restrict__ partials) {
+  pclndt_hessian_body(tg, leaves, src, n, per, P, partials);
+}
+
+// ---------------------------------------------------------------------------
+// Batched registration: every object's solver (ndtomp::NdtMachine, pclndt_host.h) lives in device memory.  One launch evaluates
+// the pass each live object is waiting for (its pose and angle tables are in its machine), the step launch that follows sums the
+// workgroup rows in the fixed order of k_pclndt_reduce and advances the machines -- Newton direction, More-Thuente trial, the
+// convergence test -- so the host takes no decision between evaluations (it reads one status byte per object, a round behind).
+// grid = (max workgroups of an object, objects)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pclndt_batch_pass(const NdtObject* __restrict__ objs, const ndtomp::NdtMachine* __restrict__ ms) {
+  const NdtObject ob = objs[blockIdx.y];
+  const int req = ms[blockIdx.y].request;
+  if (req < 0 || blockIdx.x >= (uint32_t)ob.nblocks) return;
+  const NdtOmpParams& P = ms[blockIdx.y].P;
+  if (req == 0) pclndt_derivatives_body<true>(ob.tg, ob.leaves, ob.src, ob.n, ob.per, P, ob.partials);
+  else if (req == 1) pclndt_derivatives_body<false>(ob.tg, ob.leaves, ob.src, ob.n, ob.per, P, ob.partials);
+  else pclndt_hessian_body(ob.tg, ob.leaves, ob.src, ob.n, ob.per, P, ob.partials);
+}
+
+// JacobiSVD<Matrix6d>(H, ComputeFullU | ComputeFullV).solve(b) by the whole workgroup: the arithmetic of pcm::svd_solve6 /
+// jacobi_svd<6> (dev_linalg.h) element for element -- every rotation updates 6 independent entries of w (twice), U and V, which
+// here are 18 lanes instead of 18 turns of one lane's loop; the 2x2 step and every decision are recomputed by all lanes from the
+// same LDS values (uniform control flow, so the barriers are safe).  One lane alone needs ~160 us for a 6 x 6 matrix (a chain of
+// dependent double operations), which was most of a solver round.
+struct SvdScratch { double W[6][6], U[6][6], V[6][6]; };
+__device__ void svd_solve6_block(const double* H, const double* b, double* x, SvdScratch& m) {
+  const int t = threadIdx.x;
+  const double precision = 2.0 * DBL_EPSILON, considerAsZero = DBL_MIN;
+  double scale = 0.0;
+  bool finite = true;
+  for (int i = 0; i < 36; i++) {
+    const double a = fabs(H[i]);
+    if (!(a <= DBL_MAX)) finite = false;
+    if (a > scale) scale = a;
+  }
+  if (!finite) {   // InvalidInput: singular values 0 -> rank 0 -> the zero vector
+    if (t < 6) x[t] = 0.0;
+    __syncthreads();
+    return;
+  }
+  if (scale == 0.0) scale = 1.0;
+  if (t < 36) {
+    const int i = t / 6, j = t % 6;
+    m.W[i][j] = H[t] / scale;
+    m.U[i][j] = m.V[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double maxDiag = 0.0;
+  for (int i = 0; i < 6; i++) if (fabs(m.W[i][i]) > maxDiag) maxDiag = fabs(m.W[i][i]);
+  bool finished = false;
+  while (!finished) {
+    finished = true;
+    for (int p = 1; p < 6; p++) {
+      for (int q = 0; q < p; q++) {
+        double thr = precision * maxDiag;
+        if (considerAsZero > thr) thr = considerAsZero;
+        if (fabs(m.W[p][q]) > thr || fabs(m.W[q][p]) > thr) {
+          finished = false;
+          double m00 = m.W[p][p], m01 = m.W[p][q], m10 = m.W[q][p], m11 = m.W[q][q];
+          double r1c, r1s;
+          const double tt = m00 + m11, d = m10 - m01;
+          if (fabs(d) < DBL_MIN) { r1s = 0.0; r1c = 1.0; }
+          else { const double u = tt / d; const double tmp = sqrt(1.0 + u * u); r1s = 1.0 / tmp; r1c = u / tmp; }
+          plane_rot(m00, m10, r1c, r1s);
+          plane_rot(m01, m11, r1c, r1s);
+          double jrc, jrs;
+          make_jacobi(m00, m01, m11, jrc, jrs);
+          const double tc = jrc, ts = -jrs;
+          const double jlc = r1c * tc - r1s * ts, jls = r1c * ts + r1s * tc;
+          __syncthreads();   // every lane has read the four pivots (and the test above) before anyone rotates them
+          if (t < 6) plane_rot(m.W[p][t], m.W[q][t], jlc, jls);
+          else if (t < 12) plane_rot(m.U[t - 6][p], m.U[t - 6][q], jlc, jls);
+          else if (t < 18) plane_rot(m.V[t - 12][p], m.V[t - 12][q], jrc, -jrs);
+          __syncthreads();
+          if (t < 6) plane_rot(m.W[t][p], m.W[t][q], jrc, -jrs);
+          __syncthreads();
+          const double mx = fabs(m.W[p][p]) > fabs(m.W[q][q]) ? fabs(m.W[p][p]) : fabs(m.W[q][q]);
+          if (mx > maxDiag) maxDiag = mx;
+        }
+      }
+    }
+  }
+  if (t == 0) {   // the serial tail of jacobi_svd<6> and svd_solve6: signs, scale, descending order, rank, solve
+    double sv[6];
+    for (int i = 0; i < 6; i++) {
+      const double a = m.W[i][i];
+      sv[i] = fabs(a);
+      if (a < 0.0) for (int r = 0; r < 6; r++) m.U[r][i] = -m.U[r][i];
+    }
+    for (int i = 0; i < 6; i++) sv[i] *= scale;
+    for (int i = 0; i < 6; i++) {
+      int pos = i;
+      double mxv = sv[i];
+      for (int j = i + 1; j < 6; j++) if (sv[j] > mxv) { mxv = sv[j]; pos = j; }
+      if (mxv == 0.0) break;
+      if (pos != i) {
+        const double tv = sv[i]; sv[i] = sv[pos]; sv[pos] = tv;
+        for (int r = 0; r < 6; r++) {
+          const double u = m.U[r][pos]; m.U[r][pos] = m.U[r][i]; m.U[r][i] = u;
+          const double v = m.V[r][pos]; m.V[r][pos] = m.V[r][i]; m.V[r][i] = v;
+        }
+      }
+    }
+    double pre = sv[0] * (6.0 * DBL_EPSILON);
+    if (DBL_MIN > pre) pre = DBL_MIN;
+    int nz = 6;
+    for (int i = 0; i < 6; i++) if (sv[i] == 0.0) { nz = i; break; }
+    int rank = nz;
+    while (rank > 0 && sv[rank - 1] < pre) rank--;
+    double tmp[6];
+    for (int j = 0; j < rank; j++) {
+      const double p0 = m.U[0][j] * b[0], p1 = m.U[1][j] * b[1], p2 = m.U[2][j] * b[2], p3 = m.U[3][j] * b[3], p4 = m.U[4][j] * b[4], p5 = m.U[5][j] * b[5];
+      tmp[j] = (p0 + (p2 + p4)) + (p1 + (p3 + p5));
+    }
+    for (int j = 0; j < rank; j++) tmp[j] = (1.0 / sv[j]) * tmp[j];
+    for (int i = 0; i < 6; i++) {
+      double sacc = 0.0;
+      if (rank > 0) { sacc = m.V[i][0] * tmp[0]; for (int j = 1; j < rank; j++) sacc = sacc + m.V[i][j] * tmp[j]; }
+      x[i] = sacc;
+    }
+  }
+  __syncthreads();
+}
+
+// grid = objects, block = 256 (one wave per SIMD: the solver step of thread 0 keeps its 6 x 6 matrices in registers)
+__global__ void __launch_bounds__(256) k_pclndt_batch_step(const NdtObject* __restrict__ objs, ndtomp::NdtMachine* __restrict__ ms, unsigned char* __restrict__ flags_row) {
+  __shared__ double s_grp[16][kNdtStride];
+  __shared__ double s_row[kNdtStride];
+  const int o = blockIdx.x;
+  if (ms[o].request >= 0) {
+    const NdtObject ob = objs[o];
+    // 16 row groups x 64 columns (48 used), each group summed in row order, then the groups in order: as k_pclndt_reduce
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+      const int j = idx & 63, r = idx >> 6;
+      if (j < kNdtStride) {
+        double v = 0.0;
+        for (int b = r; b < ob.nblocks; b += 16) v += gload_d(ob.partials + (size_t)b * kNdtStride + j);
+        s_grp[r][j] = v;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kNdtStride) {
+      double t = 0.0;
+      for (int k = 0; k < 16; k++) t += s_grp[k][threadIdx.x];
+      s_row[threadIdx.x] = t;
+    }
+    __syncthreads();
+    // the Newton direction the step may ask for, by the whole workgroup: H and g of this evaluation (phase LS_HESS: the row holds
+    // H only, g is the machine's).  Phase LS_ITER never reaches a Newton step in the same turn.
+    __shared__ SvdScratch s_svd;
+    __shared__ double s_mg[6], s_delta[6];
+    const int phase = ms[o].phase;
+    const bool want = phase != ndtomp::NDT_PH_LS_ITER;
+    if (want) {
+      if (threadIdx.x < 6) s_mg[threadIdx.x] = -(phase == ndtomp::NDT_PH_LS_HESS ? ms[o].cur.g[threadIdx.x] : s_row[36 + threadIdx.x]);
+      __syncthreads();
+      svd_solve6_block(s_row, s_mg, s_delta, s_svd);
+    }
+    if (threadIdx.x == 0) ndtomp::ndt_machine_advance(ms[o], s_row, want ? s_delta : nullptr);
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(flags_row + o, (unsigned char)(ms[o].request >= 0 ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
@@ -414,8 +587,24 @@ int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out
   return PCM_OK;
 }
 
+void launch_pclndt_batch_round(hipStream_t stream, const NdtObject* d_objs, ndtomp::NdtMachine* d_ms, int nobj, int max_blocks, unsigned char* d_flags_row) {
+  k_pclndt_batch_pass<<<dim3((unsigned)max_blocks, (unsigned)nobj), 256, 0, stream>>>(d_objs, d_ms);
+  k_pclndt_batch_step<<<nobj, 256, 0, stream>>>(d_objs, d_ms, d_flags_row);
+}
+
+NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, double* d_partials) {
+  NdtObject ob{};
+  ob.tg = view_of2(map); ob.leaves = leaves; ob.src = src; ob.n = n;
+  ob.nblocks = pclndt_workgroups(n, &ob.per);
+  ob.partials = d_partials;
+  return ob;
+}
+
 int pclndt_workgroups(uint32_t n, uint32_t* per_out) {
-  uint32_t per = ((n / 1024 + 255) / 256) * 256;
+  // ~100 workgroups per 100k-point scan, 4 points per lane: the 43-sum workgroup reduction is paid once per 1024 points (one point
+  // per lane spent more time reducing than evaluating: 1243 -> 1600 registrations/s on 32 objects, profiles/r02_ndt_config4.json).
+  // A function of the object's own size only, so a batch sums in the order its objects would alone.
+  uint32_t per = ((n / 128 + 255) / 256) * 256;
   per = per < 256 ? 256 : (per > 2048 ? 2048 : per);
   *per_out = per;
   return (int)((n + per - 1) / per);

@@ -743,27 +743,131 @@ auto make_ndt_solver(pcm_ctx* c) {
   return s;
 }
 
-// pclomp::NormalDistributionsTransform::computeTransformation  (ndt_omp_impl.hpp:69-156)
+// buffers of a batched pclomp NDT registration, owned by the first context of the batch
+struct NdtBatchWs {
+  NdtObject* d_objs = nullptr;
+  ndtomp::NdtMachine* d_ms = nullptr;
+  NdtObject* h_objs = nullptr;            // pinned
+  ndtomp::NdtMachine* h_ms = nullptr;     // pinned
+  unsigned char* h_flags = nullptr;       // mapped pinned: [round][object] status bytes of k_pclndt_batch_step
+  unsigned char* d_flags = nullptr;
+  int cap = 0;
+  size_t cap_flags = 0;
+};
+
+void free_ndt_batch_ws(void* p) {
+  NdtBatchWs* w = static_cast<NdtBatchWs*>(p);
+  if (!w) return;
+  if (w->d_objs) hipFree(w->d_objs);
+  if (w->d_ms) hipFree(w->d_ms);
+  if (w->h_objs) hipHostFree(w->h_objs);
+  if (w->h_ms) hipHostFree(w->h_ms);
+  if (w->h_flags) hipHostFree(w->h_flags);
+  delete w;
+}
+
+// pclomp::NormalDistributionsTransform::computeTransformation (ndt_omp_impl.hpp:69-156) for n objects: their solvers run on the
+// device (ndtomp::NdtMachine, pclndt_host.h), one derivatives launch + one step launch per round for all of them
+int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_result* res) {
+  pcm_ctx* c0 = ctxs[0];
+  for (int i = 0; i < n; i++) {
+    int rc = prepare(ctxs[i]);
+    if (rc != PCM_OK) { if (i) c0->err = ctxs[i]->err; return rc; }
+    if (ctxs[i]->stream != c0->stream) HIPCK(c0, hipStreamSynchronize(ctxs[i]->stream));   // its map / leaves were built on its own stream
+  }
+  if (!c0->ndt_ws) c0->ndt_ws = new (std::nothrow) NdtBatchWs();
+  if (!c0->ndt_ws) { c0->err = "out of host memory"; return PCM_ERR_HIP; }
+  NdtBatchWs& w = *static_cast<NdtBatchWs*>(c0->ndt_ws);
+  if (n > w.cap) {
+    if (w.d_objs) hipFree(w.d_objs);
+    if (w.d_ms) hipFree(w.d_ms);
+    if (w.h_objs) hipHostFree(w.h_objs);
+    if (w.h_ms) hipHostFree(w.h_ms);
+    w.d_objs = nullptr; w.d_ms = nullptr; w.h_objs = nullptr; w.h_ms = nullptr; w.cap = 0;
+    const int cap = std::max(n, 16);
+    HIPCK(c0, hipMalloc(&w.d_objs, sizeof(NdtObject) * cap));
+    HIPCK(c0, hipMalloc(&w.d_ms, sizeof(ndtomp::NdtMachine) * cap));
+    HIPCK(c0, hipHostMalloc(reinterpret_cast<void**>(&w.h_objs), sizeof(NdtObject) * cap, hipHostMallocDefault));
+    HIPCK(c0, hipHostMalloc(reinterpret_cast<void**>(&w.h_ms), sizeof(ndtomp::NdtMachine) * cap, hipHostMallocDefault));
+    w.cap = cap;
+  }
+  // an object asks for at most 12 evaluations per Newton iteration (1 + 10 trials + the Hessian pass) and runs max_iterations + 2 of them
+  int max_rounds = 2;
+  int max_blocks = 1;
+  for (int i = 0; i < n; i++) {
+    pcm_ctx* c = ctxs[i];
+    w.h_objs[i] = make_ndt_object(c->map, c->pleaf, c->src.d_pts, (uint32_t)c->src.n, c->ndt_partials);
+    max_blocks = std::max(max_blocks, (int)w.h_objs[i].nblocks);
+    ndtomp::ndt_machine_start(w.h_ms[i], guesses + 16 * (size_t)i, (double)c->cfg.ndt_step_size, c->cfg.translation_eps, (double)c->cfg.ndt_outlier_ratio,
+                              c->cfg.voxel_resolution, c->cfg.max_iterations, c->cfg.num_neighbors);
+    max_rounds = std::max(max_rounds, (c->cfg.max_iterations + 3) * 12 + 2);
+  }
+  const size_t flag_bytes = (size_t)max_rounds * (size_t)n;
+  if (flag_bytes > w.cap_flags) {
+    if (w.h_flags) hipHostFree(w.h_flags);
+    w.h_flags = nullptr; w.d_flags = nullptr; w.cap_flags = 0;
+    const size_t bytes = std::max<size_t>(flag_bytes, 65536);
+    HIPCK(c0, hipHostMalloc(reinterpret_cast<void**>(&w.h_flags), bytes, hipHostMallocMapped));
+    HIPCK(c0, hipHostGetDevicePointer(reinterpret_cast<void**>(&w.d_flags), w.h_flags, 0));
+    w.cap_flags = bytes;
+  }
+  std::memset(w.h_flags, 0, flag_bytes);
+  hipStream_t st = c0->stream;
+  HIPCK(c0, hipMemcpyAsync(w.d_objs, w.h_objs, sizeof(NdtObject) * n, hipMemcpyHostToDevice, st));
+  HIPCK(c0, hipMemcpyAsync(w.d_ms, w.h_ms, sizeof(ndtomp::NdtMachine) * n, hipMemcpyHostToDevice, st));
+  int rounds = 0;
+  for (int r = 0; r < max_rounds; r++) {
+    launch_pclndt_batch_round(st, w.d_objs, w.d_ms, n, max_blocks, w.d_flags + (size_t)r * n);
+    rounds = r + 1;
+    if (r >= 1) {   // look one round behind, so that the next round is queued before the host knows whether it is needed
+      volatile unsigned char* row = w.h_flags + (size_t)(r - 1) * n;
+      bool any_active = false;
+      const auto t_start = std::chrono::steady_clock::now();
+      auto next_query = t_start + std::chrono::milliseconds(5);
+      for (int i = 0; i < n; i++) {
+        unsigned spins = 0;
+        while (row[i] == 0) {
+          if ((++spins & 0xfff) == 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (now - t_start > std::chrono::seconds(20)) { (void)hipStreamSynchronize(st); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
+            if (now >= next_query) {
+              next_query = now + std::chrono::milliseconds(5);
+              if (hipStreamQuery(st) == hipSuccess && row[i] == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
+            }
+          }
+        }
+        any_active |= row[i] == 1;
+      }
+      if (!any_active) break;
+    }
+  }
+  HIPCK(c0, hipGetLastError());
+  HIPCK(c0, hipMemcpyAsync(w.h_ms, w.d_ms, sizeof(ndtomp::NdtMachine) * n, hipMemcpyDeviceToHost, st));
+  HIPCK(c0, hipStreamSynchronize(st));
+  int worst = PCM_OK;
+  for (int i = 0; i < n; i++) {
+    const ndtomp::NdtMachine& m = w.h_ms[i];
+    pcm_result* out = &res[i];
+    std::memset(out, 0, sizeof(*out));
+    for (int k = 0; k < 16; k++) { out->T[k] = m.P.T[k]; out->T64[k] = (double)m.P.T[k]; }
+    std::memcpy(out->H, m.cur.H, sizeof(out->H));   // hessian_eigen_
+    out->cost = m.cur.score;                        // trans_probability_ * N
+    out->iterations = m.nr;
+    out->converged = m.converged;
+    out->num_linearize = m.n_deriv;
+    out->num_compute_error = m.n_hess;
+    out->status = m.request < 0 ? PCM_OK : PCM_ERR_HIP;   // a machine still asking after max_rounds cannot happen (bounded loops)
+    if (out->status != PCM_OK) { worst = out->status; c0->err = "pclomp NDT solver did not finish within its round budget"; }
+    ctxs[i]->stats.linearize_launches += (uint64_t)(m.n_deriv + m.n_hess);
+    ctxs[i]->stats.point_passes += (uint64_t)(m.n_deriv + m.n_hess) * ctxs[i]->src.n;
+  }
+  (void)rounds;
+  return worst;
+}
+
 int pclndt_align(pcm_ctx* c, const float guess[16], pcm_result* out) {
-  int rc = prepare(c);
-  if (rc != PCM_OK) return rc;
-  auto solver = make_ndt_solver(c);
-  ndtomp::Eval last{};
-  int iters = 0, conv = 0;
-  float g16[16];
-  std::memcpy(g16, guess, sizeof(g16));
-  rc = solver.align(g16, &last, &iters, &conv);
-  if (rc != PCM_OK) return rc;
-  std::memset(out, 0, sizeof(*out));
-  for (int i = 0; i < 16; i++) { out->T[i] = solver.P.T[i]; out->T64[i] = (double)solver.P.T[i]; }
-  std::memcpy(out->H, last.H, sizeof(out->H));   // hessian_eigen_
-  out->cost = last.score;                        // trans_probability_ * N
-  out->iterations = iters;
-  out->converged = conv;
-  out->num_linearize = solver.n_deriv;
-  out->num_compute_error = solver.n_hess;
-  out->status = PCM_OK;
-  return PCM_OK;
+  pcm_ctx* one[1] = {c};
+  return pclndt_align_batch(one, 1, guess, out);
 }
 
 }  // namespace
@@ -834,6 +938,8 @@ void pcm_destroy(pcm_ctx* c) {
     c->tgt.release();
     if (c->src_order) hipFree(c->src_order);
     if (c->lio_aux) hipFree(c->lio_aux);
+    free_ndt_batch_ws(c->ndt_ws);
+    c->ndt_ws = nullptr;
     c->map.release();
     c->srcmap.release();
     if (c->corr) hipFree(c->corr);
@@ -1252,33 +1358,14 @@ int pcm_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resul
     if (rc != PCM_OK) return rc;
   }
   if (ctxs[0]->cfg.model == PCM_MODEL_NDT_OMP) {
-    // the Newton / line-search control flow of pclomp NDT is per object (a host decision per evaluation): no lock-step
-    // batch.  The objects are independent and each owns its stream, so up to 8 host threads drive them side by side and
-    // their (small) derivative kernels overlap on the device.
     std::vector<pcm_result> res((size_t)n);
-    std::vector<int> rcs((size_t)n, PCM_OK);
     for (int i = 0; i < n; i++) {
       if (ctxs[i]->cfg.model != PCM_MODEL_NDT_OMP) { ctxs[0]->err = "all contexts of a batch must share the model"; return PCM_ERR_INVALID_ARGUMENT; }
+      if (ctxs[i]->device != ctxs[0]->device) { ctxs[0]->err = "all contexts of a batch must live on one device"; return PCM_ERR_INVALID_ARGUMENT; }
       for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) { ctxs[0]->err = "a context appears twice in the batch"; return PCM_ERR_INVALID_ARGUMENT; }
     }
-    const int nthreads = std::min(n, 8);
-    std::atomic<int> next{0};
-    auto worker = [&]() {
-      for (;;) {
-        const int i = next.fetch_add(1);
-        if (i >= n) break;
-        rcs[(size_t)i] = pclndt_align(ctxs[i], guesses + 16 * (size_t)i, &res[(size_t)i]);
-        if (rcs[(size_t)i] != PCM_OK) res[(size_t)i].status = rcs[(size_t)i];
-      }
-    };
-    if (nthreads <= 1) worker();
-    else {
-      std::vector<std::thread> th;
-      for (int t = 0; t < nthreads; t++) th.emplace_back(worker);
-      for (auto& t : th) t.join();
-    }
-    int worst = PCM_OK;
-    for (int i = 0; i < n; i++) if (rcs[(size_t)i] != PCM_OK) { worst = rcs[(size_t)i]; if (i) ctxs[0]->err = ctxs[i]->err; }
+    const int worst = pclndt_align_batch(ctxs, n, guesses, res.data());
+    if (worst != PCM_OK && res.empty()) return worst;
     if (host_out) std::memcpy(host_out, res.data(), sizeof(pcm_result) * (size_t)n);
     if (device_out && hipMemcpy(device_out, res.data(), sizeof(pcm_result) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) return PCM_ERR_HIP;
     return worst;

@@ -207,6 +207,16 @@ struct PairDesc {
   unsigned int* counter;  // arrival tickets of the round's workgroups (0 between rounds)
 };
 
+// one object of a batched pclomp NDT registration (pclndt.hip)
+struct NdtObject {
+  TargetView tg;
+  const PclLeaf* leaves;
+  const float4* src;
+  uint32_t n, per;        // scan points, points per workgroup
+  int32_t nblocks, pad;   // workgroup rows of a pass
+  double* partials;       // [nblocks][kNdtStride]
+};
+
 // pair handled by grid entry b
 #define PCM_PAIR_OF(kp, b) ((kp).use_list ? (int)(kp).active[(b)] : (int)(b))
 

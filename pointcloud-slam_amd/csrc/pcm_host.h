@@ -114,6 +114,10 @@ int build_vgc_voxels(hipStream_t stream, const TargetMap& map, const double* d_c
 // pclndt.hip: pclomp NDT leaves and derivative passes (pass 0: score+gradient+Hessian, 1: score+gradient, 2: double Hessian only)
 int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err);
 int pclndt_workgroups(uint32_t n, uint32_t* per_out);
+namespace ndtomp { struct NdtMachine; }
+NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, double* d_partials);
+// one round of a batched pclomp NDT registration: the pass every live object waits for, then the sums + solver step per object
+void launch_pclndt_batch_round(hipStream_t stream, const NdtObject* d_objs, ndtomp::NdtMachine* d_ms, int nobj, int max_blocks, unsigned char* d_flags_row);
 void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
                         double gauss_d3 = 0.0);   // pass 3: calculateScore (needs gauss_d3)
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations, int window, unsigned int* d_queue);
@@ -167,6 +171,7 @@ struct pcm_ctx {
   float2* lio_aux = nullptr;       // PCM_FLAG_LIO_REFERENCE_SEMANTICS: residuals_ / point_selected_surf_ of LaserMapping, in the caller's scan order;
   size_t lio_aux_n = 0, lio_aux_cap = 0;   // they outlive the scan (std::vector::resize semantics, laser_mapping.cc:337-338)
   void* ws = nullptr;   // batch workspace owned by this context (pcm_api.hip)
+  void* ndt_ws = nullptr;   // pclomp NDT: objects + solver machines of a batch (pcm_api.hip)
   char* pre_arena = nullptr;   // grow-only device scratch of the pre-processing operators
   size_t pre_arena_cap = 0;
   char* bfgs = nullptr;        // GICP-BFGS functor: packed correspondence records + partial sums (gicp_bfgs.hip)

@@ -9,6 +9,8 @@ ap.add_argument("--scan", type=int, default=100_000)
 ap.add_argument("--scans", type=int, default=8, help="scans registered against the one map (one batch)")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--cpu", type=int, default=1)
+ap.add_argument("--lib", default="", help="A/B: load this build of the library")
+ap.add_argument("--eps", type=float, default=0.01, help="pclomp NDT transformation epsilon: 0.01 at the call sites (jueying_slam/src/localization.cpp:170-175), 0.1 the class default")
 ap.add_argument("--models", default="NDT_OMP,NDT_OMP_KDTREE,NDT_D2D,NDT_P2D")
 a = ap.parse_args()
 synth = importlib.import_module("pointcloud-slam_amd.synth")
@@ -21,6 +23,8 @@ for i in range(a.scans):
     scans.append(sc); gts.append(T); guesses.append(synth.perturb_pose(T, 99 + i).astype(np.float32))
 import torch
 import pointcloud_slam_amd as pcm
+if a.lib:
+    pcm.capi.library_path = lambda: os.path.abspath(a.lib)
 d_map = torch.from_numpy(submap).cuda()
 out = {}
 for mname in a.models.split(","):
@@ -29,7 +33,7 @@ for mname in a.models.split(","):
     regs = []
     t0 = time.perf_counter()
     for sc in scans:
-        r = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=nn) if model == "NDT_OMP" else pcm.NdtRegistration(0, model=model, voxel_resolution=0.5, num_neighbors=7)
+        r = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=nn, translation_eps=a.eps) if model == "NDT_OMP" else pcm.NdtRegistration(0, model=model, voxel_resolution=0.5, num_neighbors=7)
         r.set_input_target(d_map); regs.append(r)
     d_scans = [torch.from_numpy(s).cuda() for s in scans]
     for r, s in zip(regs, d_scans):
@@ -44,11 +48,11 @@ for mname in a.models.split(","):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.reps
     errs = [float(np.linalg.norm((np.linalg.inv(g) @ x.T64)[:3, 3])) for g, x in zip(gts, res)]
     out[mname] = {"registrations_per_s": a.scans / dt, "ms_per_batch": 1e3 * dt, "cold_s": t_cold, "iterations": [x.iterations for x in res], "evaluations": [x.num_linearize for x in res],
-                  "converged": [int(x.converged) for x in res], "err_vs_gt_m": [round(e, 3) for e in errs], "target_voxels": regs[0].stats()["target_voxels"]}
+                  "converged": [int(x.converged) for x in res], "transformation_epsilon": a.eps if model == "NDT_OMP" else None, "err_vs_gt_m": [round(e, 3) for e in errs], "target_voxels": regs[0].stats()["target_voxels"]}
     if a.cpu:
         from oracle import Oracle
         from oracle.loader import result_T
-        okw = dict(translation_eps=0.1, max_iterations=35) if model == "NDT_OMP" else {}
+        okw = dict(translation_eps=a.eps, max_iterations=35) if model == "NDT_OMP" else {}
         o = Oracle(model, "LM", voxel_resolution=0.5, num_neighbors=nn, num_threads=min(16, len(os.sched_getaffinity(0))), **okw)
         t0 = time.perf_counter(); o.set_input_target(submap); o.set_input_source(scans[0])
         if model == "NDT_OMP":
