@@ -291,6 +291,15 @@ int pcm_voxel_downsample(pcm_ctx *ctx, const void *points, size_t n, size_t stri
 int pcm_gicp_bfgs_set_correspondences(pcm_ctx *ctx, const void *src, size_t n_src, const void *tgt, size_t n_tgt, size_t stride_bytes, const int32_t *idx_src,
                                       const int32_t *idx_tgt, size_t m, const float *mahalanobis, int memory);
 int pcm_gicp_bfgs_fdf(pcm_ctx *ctx, const float *base_T, const double *x, int mode, double *f, double *g);
+/* The correspondence step of pclomp GICP's computeTransformation on the device (gicp_omp_impl.hpp:405-472), for a GICP context whose
+ * source / target are *input_ / *target_ (regularization PCM_REG_PCLOMP = pclomp's computeCovariances): output = guess * input,
+ * query = transformation * output, exact nearest target point within max_corr_dist, mahalanobis_ = (R C1 R^T + C2)^-1 cast to
+ * float; the pairs, in source order, become the record set pcm_gicp_bfgs_fdf evaluates (cloud_src = output, as at :479) without
+ * leaving the device.  `transformation`, `guess`: row-major 4x4 (transformation_, guess).  *m = number of pairs. */
+int pcm_gicp_bfgs_update_correspondences(pcm_ctx *ctx, const float *transformation, const float *guess, size_t *m);
+/* parity hook: the pairs of the last update (source_indices / target_indices, :466-472) and their 3x3 float matrices (row-major);
+ * any pointer may be NULL */
+int pcm_gicp_bfgs_get_correspondences(pcm_ctx *ctx, int32_t *idx_src, int32_t *idx_tgt, float *mahalanobis9, size_t capacity);
 
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel

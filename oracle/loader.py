@@ -171,6 +171,17 @@ class Oracle:
         lib().orc_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), HTH.ctypes.data, HTh.ctypes.data, C.byref(n), C.byref(s2))
         return HTH, HTh, n.value, s2.value
 
+    def gicp_bfgs_correspondences(self, transformation, guess):
+        """pclomp GICP correspondence step: (idx_src, idx_tgt, mahalanobis (m,3,3) float32) in source order."""
+        L = lib()
+        L.orc_gicp_bfgs_correspondences.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_long)]
+        n = self._keep["s"].shape[0]
+        T = np.ascontiguousarray(transformation, np.float32); G = np.ascontiguousarray(guess, np.float32)
+        isrc = np.zeros(n, np.int32); itgt = np.zeros(n, np.int32); M = np.zeros((n, 9), np.float32); m = C.c_long()
+        if L.orc_gicp_bfgs_correspondences(self._h, T.ctypes.data, G.ctypes.data, isrc.ctypes.data, itgt.ctypes.data, M.ctypes.data, C.byref(m)) != 0:
+            raise RuntimeError("orc_gicp_bfgs_correspondences")
+        return isrc[:m.value].copy(), itgt[:m.value].copy(), M[:m.value].reshape(-1, 3, 3).copy()
+
     def set_neighbor_radius(self, radius):
         """NeighborSearchMethod::DIRECT_RADIUS of the CUDA-core models (radius in voxels; 0 = off)."""
         lib().orc_set_neighbor_radius(self._h, float(radius))

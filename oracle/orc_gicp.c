@@ -498,3 +498,43 @@ double orc_fitness_score(void *h, const float T[16], double max_range) {
   grid_free(&g);
   return nr > 0 ? sum / (double)nr : DBL_MAX;
 }
+
+/* pclomp GICP-BFGS: the correspondence step of computeTransformation  (ndt_omp/include/pclomp/gicp_omp_impl.hpp:405-472).
+ * The handle is a GICP oracle whose source / target are *input_ / *target_ (covariances with ORC_REG_PCLOMP = pclomp's
+ * computeCovariances).  Returns the pairs in source order and mahalanobis_[source] as 9 floats (row-major 3x3 block). */
+int orc_gicp_bfgs_correspondences(void *h, const float transformation[16], const float guess[16], int *idx_src, int *idx_tgt, float *maha9, long *m_out) {
+  oracle *o = (oracle *)h;
+  if (o->cfg.model != ORC_MODEL_GICP) return -1;
+  orc_gicp_state *s = st(o);
+  orc_gicp_prepare(o);
+  const double thr2 = o->cfg.max_corr_dist * o->cfg.max_corr_dist;   /* dist_threshold = corr_dist_threshold_^2  :397 */
+  double R[9];
+  for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {           /* transform_R(i,j) += double(transformation_(i,k)) * double(guess(k,j))  :416-419 */
+    double v = 0.0;
+    for (int k = 0; k < 4; k++) v += (double)transformation[a * 4 + k] * (double)guess[k * 4 + b];
+    R[a * 3 + b] = v;
+  }
+  long m = 0;
+  for (long i = 0; i < o->src.n; i++) {   /* serial: the result is sorted by source index anyway (:466-472) */
+    const float *p = o->src.xyz + 3 * i;
+    float out[3], q[3];
+    for (int a = 0; a < 3; a++) out[a] = guess[a * 4 + 0] * p[0] + (guess[a * 4 + 1] * p[1] + (guess[a * 4 + 2] * p[2] + guess[a * 4 + 3]));   /* pcl::transformPointCloud(output, output, guess)  :398 */
+    /* query = transformation_ * output[i]: Matrix4f * Vector4f, accumulated column by column (etor_product_packet_impl; CORE-1)  :428 */
+    for (int a = 0; a < 3; a++) q[a] = ((transformation[a * 4 + 0] * out[0] + transformation[a * 4 + 1] * out[1]) + transformation[a * 4 + 2] * out[2]) + transformation[a * 4 + 3] * 1.f;
+    int id; float d2;
+    const int found = grid_knn(&s->tgt_grid, &o->tgt, q, 1, thr2, &id, &d2);
+    if (!(found == 1 && (double)d2 < thr2)) continue;     /* nn_dists[0] < dist_threshold  :437 */
+    const double *C1 = s->src_cov + 9 * i, *C2 = s->tgt_cov + 9 * (long)id;
+    double M[9], tmp[9], inv[9];
+    /* M = R * C1; temp = M * R^T; temp += C2  (:445-449): Matrix3d lazy products, each coefficient the fixed-size 3-term tree t0 + (t1 + t2) */
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) M[a * 3 + b] = R[a * 3 + 0] * C1[0 * 3 + b] + (R[a * 3 + 1] * C1[1 * 3 + b] + R[a * 3 + 2] * C1[2 * 3 + b]);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) tmp[a * 3 + b] = (M[a * 3 + 0] * R[b * 3 + 0] + (M[a * 3 + 1] * R[b * 3 + 1] + M[a * 3 + 2] * R[b * 3 + 2])) + C2[a * 3 + b];
+    orc_eig_inv3d(tmp, inv);                                          /* temp.inverse()  :451 */
+    if (idx_src) idx_src[m] = (int)i;
+    if (idx_tgt) idx_tgt[m] = id;
+    if (maha9) for (int a = 0; a < 9; a++) maha9[9 * m + a] = (float)inv[a];   /* M.cast<float>()  :452 */
+    m++;
+  }
+  if (m_out) *m_out = m;
+  return 0;
+}

@@ -13,7 +13,7 @@ SYMBOLS = [
     "pcm_abi_version", "pcm_default_config", "pcm_create", "pcm_destroy", "pcm_last_error",
     "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
     "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
-    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_get_lio_members", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_ndt_derivatives", "pcm_ndt_score", "pcm_fitness_score", "pcm_undistort", "pcm_voxel_downsample", "pcm_gicp_bfgs_set_correspondences", "pcm_gicp_bfgs_fdf", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
+    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_get_lio_members", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_ndt_derivatives", "pcm_ndt_score", "pcm_fitness_score", "pcm_undistort", "pcm_voxel_downsample", "pcm_gicp_bfgs_set_correspondences", "pcm_gicp_bfgs_fdf", "pcm_gicp_bfgs_update_correspondences", "pcm_gicp_bfgs_get_correspondences", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
@@ -135,6 +135,8 @@ def load_library():
     L.pcm_voxel_downsample.argtypes = [vp, vp, sz, sz, C.c_int, C.c_float, vp, sz, C.POINTER(sz)]
     L.pcm_gicp_bfgs_set_correspondences.argtypes = [vp, vp, sz, vp, sz, sz, vp, vp, sz, vp, C.c_int]
     L.pcm_gicp_bfgs_fdf.argtypes = [vp, vp, vp, C.c_int, C.POINTER(C.c_double), vp]
+    L.pcm_gicp_bfgs_update_correspondences.argtypes = [vp, vp, vp, C.POINTER(sz)]
+    L.pcm_gicp_bfgs_get_correspondences.argtypes = [vp, vp, vp, vp, sz]
     L.pcm_undistort.argtypes = [vp, vp, sz, sz, sz, C.c_int, vp, C.c_int, C.POINTER(PcmLioState)]
     L.pcm_align_batch.argtypes = [C.POINTER(vp), i32, vp, vp, vp]
     L.pcm_set_profiling.argtypes = [vp, i32]

@@ -20,6 +20,9 @@
 #include "pcm_host.h"
 #include "dev_linalg.h"
 
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
 namespace pcm {
 
 namespace {
@@ -869,6 +872,124 @@ __global__ void __launch_bounds__(256) k_fitness(TargetView tg, int coord_mode, 
     out[2 * blockIdx.x + 0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
     out[2 * blockIdx.x + 1] = ((s_cnt[0] + s_cnt[1]) + s_cnt[2]) + s_cnt[3];
   }
+}
+
+// ---------------------------------------------------------------------------
+// pclomp GICP-BFGS, correspondence step of computeTransformation (ndt_omp/include/pclomp/gicp_omp_impl.hpp:405-462): for every
+// source point i -- output[i] = guess * input[i] (pcl::transformPointCloud, float), query = transformation_ * output[i] (float
+// Matrix4f * Vector4f), exact nearest target point, kept when nn_dist < corr_dist_threshold^2 -- the Mahalanobis matrix
+// M = (R C1 R^T + C2)^-1 in double (R = rotation of transformation_ * guess formed in double, :416-421), cast to float.  Written
+// per SOURCE INDEX (the covariances live in map order; `order` maps back), then compacted in source order (the reference sorts
+// its pairs by source index, :466-472) straight into the functor's four-plane records (gicp_bfgs.hip): no host copy of the set.
+// ---------------------------------------------------------------------------
+struct BfgsCorrXf { float G[12]; float T[12]; double R[9]; double max_sq; };
+
+__global__ void __launch_bounds__(256) k_bfgs_correspond(TargetView tg, int coord_mode, const float4* __restrict__ src, const uint32_t* __restrict__ src_order, uint32_t n,
+                                                         const double* __restrict__ src_cov, const double* __restrict__ tgt_cov, const uint32_t* __restrict__ tgt_order, BfgsCorrXf X,
+                                                         uint32_t* __restrict__ flag, float4* __restrict__ rec /* 4 planes of n */, int32_t* __restrict__ tgt_idx) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t i = src_order[k];
+  const float4 p = gload4(src + k);
+  float o[3], qf[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) o[a] = X.G[a * 4 + 0] * p.x + (X.G[a * 4 + 1] * p.y + (X.G[a * 4 + 2] * p.z + X.G[a * 4 + 3]));      // pcl::transformPointCloud
+#pragma unroll
+  for (int a = 0; a < 3; a++) qf[a] = ((X.T[a * 4 + 0] * o[0] + X.T[a * 4 + 1] * o[1]) + X.T[a * 4 + 2] * o[2]) + X.T[a * 4 + 3] * 1.f;   // Matrix4f * Vector4f, column by column
+  const int j = nearest1(tg, coord_mode, qf, X.max_sq);
+  flag[i] = j >= 0 ? 1u : 0u;
+  if (j < 0) return;
+  const float4 q = gload4(tg.pts + j);
+  const double* c1 = src_cov + (size_t)k * 6;
+  const double* c2 = tgt_cov + (size_t)j * 6;
+  const double C1[9] = {c1[0], c1[1], c1[2], c1[1], c1[3], c1[4], c1[2], c1[4], c1[5]};
+  const double C2[9] = {c2[0], c2[1], c2[2], c2[1], c2[3], c2[4], c2[2], c2[4], c2[5]};
+  double M[9], tmp[9], inv[9];
+  // Matrix3d lazy products, coefficient (a, b) = sum of three terms by the fixed-size tree t0 + (t1 + t2)  (CORE-1)
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) M[a * 3 + b] = X.R[a * 3 + 0] * C1[0 * 3 + b] + (X.R[a * 3 + 1] * C1[1 * 3 + b] + X.R[a * 3 + 2] * C1[2 * 3 + b]);
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = 0; b < 3; b++) tmp[a * 3 + b] = (M[a * 3 + 0] * X.R[b * 3 + 0] + (M[a * 3 + 1] * X.R[b * 3 + 1] + M[a * 3 + 2] * X.R[b * 3 + 2])) + C2[a * 3 + b];
+  inv3<double>(tmp, inv);
+  const float Mf[9] = {(float)inv[0], (float)inv[1], (float)inv[2], (float)inv[3], (float)inv[4], (float)inv[5], (float)inv[6], (float)inv[7], (float)inv[8]};
+  rec[i] = make_float4(o[0], o[1], o[2], q.x);
+  rec[(size_t)n + i] = make_float4(q.y, q.z, Mf[0], Mf[1]);
+  rec[2 * (size_t)n + i] = make_float4(Mf[2], Mf[3], Mf[4], Mf[5]);
+  rec[3 * (size_t)n + i] = make_float4(Mf[6], Mf[7], Mf[8], 0.f);
+  tgt_idx[i] = (int32_t)tgt_order[j];
+}
+
+__global__ void __launch_bounds__(256) k_bfgs_compact(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, const float4* __restrict__ rec_in, const int32_t* __restrict__ tgt_idx,
+                                                      uint32_t n, uint32_t m, float4* __restrict__ rec_out, int32_t* __restrict__ idx_src, int32_t* __restrict__ idx_tgt) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const uint32_t d = pos[i];
+#pragma unroll
+  for (int pl = 0; pl < 4; pl++) rec_out[(size_t)pl * m + d] = rec_in[(size_t)pl * n + i];
+  idx_src[d] = (int32_t)i;
+  idx_tgt[d] = tgt_idx[i];
+}
+
+// returns the number of correspondences through *m_out; records + index lists land in the buffers the caller sized for n
+int gicp_bfgs_correspond_device(hipStream_t stream, const TargetMap& tmap, int coord_mode, const TargetMap& smap, const double* src_cov, const double* tgt_cov,
+                                const float* guess, const float* transformation, double max_corr_dist, float4* d_records, int32_t* d_idx_src, int32_t* d_idx_tgt, uint32_t* m_out,
+                                std::string* err) {
+  const uint32_t n = smap.num_points;
+  *m_out = 0;
+  if (n == 0) return PCM_OK;
+  BfgsCorrXf X;
+  for (int a = 0; a < 12; a++) { X.G[a] = guess[a]; X.T[a] = transformation[a]; }
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {   // transform_R(i,j) += double(transformation_(i,k)) * double(guess(k,j)), k = 0..3 from zero  (:416-419)
+      double v = 0.0;
+      for (int k = 0; k < 4; k++) v += (double)transformation[a * 4 + k] * (double)guess[k * 4 + b];
+      X.R[a * 3 + b] = v;
+    }
+  X.max_sq = max_corr_dist * max_corr_dist;
+  char* tmp = nullptr;
+  void* scan_tmp = nullptr;
+  size_t scan_bytes = 0;
+  int rc = PCM_OK;
+  uint32_t tails[2] = {0, 0};
+  TargetView tg{};
+  tg.pts = tmap.pts; tg.vox_start = tmap.vox_start; tg.bricks = tmap.bricks; tg.bmask = tmap.bmask; tg.bpref = tmap.bpref; tg.gvox = tmap.gvox;
+  tg.mask = tmap.cap - 1; tg.num_points = tmap.num_points; tg.inv_res = tmap.inv_res; tg.res = tmap.res;
+#define CK(x)                                                                    \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
+  } while (0)
+  {
+    const size_t b_flag = ((size_t)n * 4 + 255) & ~(size_t)255, b_rec = (size_t)n * 64, b_idx = b_flag;
+    CK(hipMallocAsync(reinterpret_cast<void**>(&tmp), 2 * b_flag + b_rec + b_idx, stream));
+    uint32_t* flag = reinterpret_cast<uint32_t*>(tmp);
+    uint32_t* pos = reinterpret_cast<uint32_t*>(tmp + b_flag);
+    float4* rec = reinterpret_cast<float4*>(tmp + 2 * b_flag);
+    int32_t* tidx = reinterpret_cast<int32_t*>(tmp + 2 * b_flag + b_rec);
+    k_bfgs_correspond<<<(n + 255u) / 256u, 256, 0, stream>>>(tg, coord_mode, smap.pts, smap.order, n, src_cov, tgt_cov, tmap.order, X, flag, rec, tidx);
+    CK(hipGetLastError());
+    CK(rocprim::exclusive_scan(nullptr, scan_bytes, flag, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    CK(hipMallocAsync(&scan_tmp, scan_bytes, stream));
+    CK(rocprim::exclusive_scan(scan_tmp, scan_bytes, flag, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+    CK(hipMemcpyAsync(&tails[0], flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipMemcpyAsync(&tails[1], pos + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    const uint32_t m = tails[0] + tails[1];
+    if (m) {
+      k_bfgs_compact<<<(n + 255u) / 256u, 256, 0, stream>>>(flag, pos, rec, tidx, n, m, d_records, d_idx_src, d_idx_tgt);
+      CK(hipGetLastError());
+    }
+    *m_out = m;
+  }
+done:
+  if (tmp) (void)hipFreeAsync(tmp, stream);
+  if (scan_tmp) (void)hipFreeAsync(scan_tmp, stream);
+  return rc;
+#undef CK
 }
 
 void launch_fitness(hipStream_t stream, const TargetView& tg, int coord_mode, const float4* src, uint32_t n, const float* T, double max_range, double* d_out) {

@@ -572,8 +572,6 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     }
     // per round: correspondence search + residual/Jacobian + reduction in one launch, then the tiny
     // per-pair sum + GN/LM step launch.  LM adds the (cheap) trial-cost launch + its step.
-    // GN: the last workgroup of a pair's search launch takes its step (write-through hand-off of the partial rows, kernels.hip);
-    // PCM_FLAG_SEPARATE_STEP keeps the second launch (k_finish_round) for A/B runs and the bit-equality test
     // PCM_FLAG_FUSED_STEP (off by default): the last workgroup of a pair's search launch takes the GN step (write-through hand-off of
     // the partial rows, kernels.hip).  Measured slower than the second launch at every round size, the single-pair rounds
     // included (profiles/r02_fused_step_threshold_sweep.txt): every workgroup pays a store drain and a returned atomic.
@@ -951,6 +949,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->pleaf) hipFree(c->pleaf);
     if (c->pre_arena) hipFree(c->pre_arena);
     if (c->bfgs) hipFree(c->bfgs);
+    if (c->bfgs_idx) hipFree(c->bfgs_idx);
     if (c->bfgs_host) hipHostFree(c->bfgs_host);
     if (c->ndt_partials) hipFree(c->ndt_partials);
     if (c->ndt_out) hipFree(c->ndt_out);
@@ -1243,6 +1242,59 @@ int pcm_gicp_bfgs_fdf(pcm_ctx* c, const float* base_T, const double* x, int mode
     for (int a = 0; a < 3; a++) g[a] = s[2 + a] * (2.0 / dm);
     for (int a = 0; a < 9; a++) R[a] = s[5 + a] * (2.0 / dm);
     bfgs_r_derivative(x, R, g);
+  }
+  return PCM_OK;
+}
+
+int pcm_gicp_bfgs_update_correspondences(pcm_ctx* c, const float* transformation, const float* guess, size_t* m_out) {
+  CHECK_CTX(c);
+  if (!transformation || !guess || !m_out) return PCM_ERR_INVALID_ARGUMENT;
+  *m_out = 0;
+  int rc = validate_config(c, c->cfg);
+  if (rc != PCM_OK) return rc;
+  if (c->cfg.model != PCM_MODEL_GICP) { c->err = "pcm_gicp_bfgs_update_correspondences needs the GICP model"; return PCM_ERR_UNSUPPORTED; }
+  rc = prepare(c);   // target map + its covariances, brick-major copy of the source + its covariances
+  if (rc != PCM_OK) return rc;
+  const size_t n = c->srcmap.num_points;
+  c->bfgs_m = 0;
+  const size_t need = gicp_bfgs_scratch_bytes(n);
+  if (c->bfgs_cap < need) {
+    if (c->bfgs) hipFree(c->bfgs);
+    c->bfgs = nullptr; c->bfgs_cap = 0;
+    HIPCK(c, hipMalloc(&c->bfgs, need + need / 4));
+    c->bfgs_cap = need + need / 4;
+  }
+  if (c->bfgs_idx_cap < n) {
+    if (c->bfgs_idx) hipFree(c->bfgs_idx);
+    c->bfgs_idx = nullptr; c->bfgs_idx_cap = 0;
+    HIPCK(c, hipMalloc(&c->bfgs_idx, sizeof(int32_t) * 2 * (n + n / 4 + 64)));
+    c->bfgs_idx_cap = n + n / 4 + 64;
+  }
+  uint32_t m = 0;
+  rc = gicp_bfgs_correspond_device(c->stream, c->map, coord_mode_for(c->cfg.model), c->srcmap, c->src_cov, c->tgt_cov, guess, transformation, (double)c->cfg.max_corr_dist,
+                                   reinterpret_cast<float4*>(c->bfgs), c->bfgs_idx, c->bfgs_idx + c->bfgs_idx_cap, &m, &c->err);
+  if (rc != PCM_OK) return rc;
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  c->bfgs_m = m;
+  *m_out = m;
+  return PCM_OK;
+}
+
+int pcm_gicp_bfgs_get_correspondences(pcm_ctx* c, int32_t* idx_src, int32_t* idx_tgt, float* maha9, size_t capacity) {
+  CHECK_CTX(c);
+  const size_t m = c->bfgs_m;
+  if (!c->bfgs_idx || capacity < m) { c->err = "pcm_gicp_bfgs_get_correspondences: no device-side correspondence set, or the buffers are too small"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (m == 0) return PCM_OK;
+  if (idx_src) HIPCK(c, hipMemcpy(idx_src, c->bfgs_idx, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+  if (idx_tgt) HIPCK(c, hipMemcpy(idx_tgt, c->bfgs_idx + c->bfgs_idx_cap, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+  if (maha9) {
+    std::vector<float4> r(3 * m);   // planes 1..3 of the records hold M
+    HIPCK(c, hipMemcpy(r.data(), reinterpret_cast<const float4*>(c->bfgs) + m, sizeof(float4) * 3 * m, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < m; i++) {
+      const float4 a = r[i], b = r[m + i], d = r[2 * m + i];
+      float* o = maha9 + 9 * i;
+      o[0] = a.z; o[1] = a.w; o[2] = b.x; o[3] = b.y; o[4] = b.z; o[5] = b.w; o[6] = d.x; o[7] = d.y; o[8] = d.z;
+    }
   }
   return PCM_OK;
 }

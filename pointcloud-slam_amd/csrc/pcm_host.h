@@ -85,6 +85,10 @@ constexpr int kGicpBfgsMaxBlocks = 512;   // rows of the partial-sum table
 size_t gicp_bfgs_scratch_bytes(size_t m);
 int gicp_bfgs_pack_device(hipStream_t stream, const void* d_src, const void* d_tgt, size_t stride, const int* d_idx_src, const int* d_idx_tgt, const float* d_maha, size_t m,
                           void* d_records, std::string* err);
+// correspondence step of pclomp GICP-BFGS on the device (gicp.hip): packs the functor's records in source order, returns their number
+int gicp_bfgs_correspond_device(hipStream_t stream, const TargetMap& tmap, int coord_mode, const TargetMap& smap, const double* src_cov, const double* tgt_cov,
+                                const float* guess, const float* transformation, double max_corr_dist, float4* d_records, int32_t* d_idx_src, int32_t* d_idx_tgt, uint32_t* m_out,
+                                std::string* err);
 int gicp_bfgs_fdf_device(hipStream_t stream, const void* d_records, size_t m, const float T[16], const float base[16], double* d_partials, double* d_sums, std::string* err);
 int sort_sources_batched(hipStream_t stream, const SortJob* d_jobs, int njobs, uint32_t max_n, uint32_t total, const float* d_guesses, float res,
                          SortScratch* ws, std::string* err);
@@ -176,6 +180,8 @@ struct pcm_ctx {
   size_t pre_arena_cap = 0;
   char* bfgs = nullptr;        // GICP-BFGS functor: packed correspondence records + partial sums (gicp_bfgs.hip)
   size_t bfgs_cap = 0, bfgs_m = 0;
+  int32_t* bfgs_idx = nullptr; // [2][bfgs_idx_cap] source / target index of every packed pair (device-side correspondence step)
+  size_t bfgs_idx_cap = 0;
   double* bfgs_host = nullptr; // pinned, device-visible: the 14 sums land here without a copy command
   int profiling = 0;  // bit0: HIP-event timing of residual launches, bit1: kNN counters
 };

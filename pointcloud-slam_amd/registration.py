@@ -255,6 +255,21 @@ class Registration:
         self._check(self._L.pcm_gicp_bfgs_fdf(self._h, base.ctypes.data, xx.ctypes.data, int(mode), C.byref(f), g.ctypes.data))
         return f.value, g
 
+    def gicp_bfgs_update_correspondences(self, transformation, guess) -> int:
+        """pclomp GICP's correspondence step on the device (gicp_omp_impl.hpp:405-472); the pairs become the functor's record set."""
+        T = np.ascontiguousarray(transformation, np.float32).reshape(16); G = np.ascontiguousarray(guess, np.float32).reshape(16)
+        m = C.c_size_t()
+        self._check(self._L.pcm_gicp_bfgs_update_correspondences(self._h, T.ctypes.data, G.ctypes.data, C.byref(m)))
+        self._bfgs_m = m.value
+        return m.value
+
+    def gicp_bfgs_get_correspondences(self):
+        """(idx_src, idx_tgt, mahalanobis (m,3,3) float32) of the last device-side correspondence step."""
+        m = self._bfgs_m
+        isrc = np.zeros(m, np.int32); itgt = np.zeros(m, np.int32); M = np.zeros((m, 9), np.float32)
+        self._check(self._L.pcm_gicp_bfgs_get_correspondences(self._h, isrc.ctypes.data, itgt.ctypes.data, M.ctypes.data, m))
+        return isrc, itgt, M.reshape(-1, 3, 3)
+
     def get_target(self) -> np.ndarray:
         """(M,3) current target points in insertion order."""
         n = C.c_size_t()

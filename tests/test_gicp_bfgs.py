@@ -134,3 +134,74 @@ def test_gpu_functor_matches_the_committed_vectors(pcm):
     for mode in (1, 2):
         _, gr = g.gicp_bfgs_fdf(d["base"], d["x"], mode)
         assert np.abs(gr - d["g%d" % mode]).max() <= 1e-11 * np.abs(d["g%d" % mode]).max()
+
+
+# ---- correspondence step of computeTransformation (gicp_omp_impl.hpp:405-472) -----------------------------------------
+def _corr_problem(synth, seed=5):
+    p = synth.make_pair(40 + seed, 6000, 60000, density=30.0)
+    guess = p.guess.astype(np.float32)
+    # transformation_ after a few outer iterations: a small rigid correction on top of the guess
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = Rot.from_euler("xyz", [0.004, -0.003, 0.006]).as_matrix()
+    T[:3, 3] = [0.03, -0.02, 0.01]
+    return p, T, guess
+
+
+def test_oracle_correspondence_step_against_brute_force(synth):
+    """Independent check of the oracle's step in float64 numpy: brute-force nearest neighbours, (R C1 R^T + C2)^-1 by numpy.linalg."""
+    from oracle import Oracle
+    p, T, G = _corr_problem(synth)
+    o = Oracle("GICP", "LM", regularization="PCLOMP", max_corr_dist=0.6)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    isrc, itgt, M = o.gicp_bfgs_correspondences(T, G)
+    assert 1000 < len(isrc) < len(p.scan) and np.all(np.diff(isrc) > 0)          # some rejected by the threshold; source order
+    TG = T.astype(np.float64) @ G.astype(np.float64)
+    q = p.scan[:, :3].astype(np.float64) @ TG[:3, :3].T + TG[:3, 3]
+    tgt = p.submap[:, :3].astype(np.float64)
+    sel = np.zeros(len(q), bool); sel[isrc] = True
+    rng = np.random.default_rng(0)
+    for i in rng.choice(len(q), 300, replace=False):                              # brute force on a sample (60k targets each)
+        d2 = ((tgt - q[i]) ** 2).sum(1)
+        j = int(d2.argmin())
+        if d2[j] < 0.36 * (1 - 1e-4):
+            assert sel[i] and abs(d2[itgt[np.searchsorted(isrc, i)]] - d2[j]) <= 1e-6 * max(d2[j], 1e-12)
+        elif d2[j] > 0.36 * (1 + 1e-4):
+            assert not sel[i]
+    C1 = o.covariances(False); C2 = o.covariances(True)
+    R = TG[:3, :3]
+    for k in rng.choice(len(isrc), 300, replace=False):
+        ref = np.linalg.inv(R @ C1[isrc[k]] @ R.T + C2[itgt[k]])
+        assert np.abs(M[k] - ref).max() <= 2e-6 * np.abs(ref).max()               # double arithmetic, cast to float
+
+
+@pytest.mark.gpu
+def test_gpu_correspondence_step_matches_the_oracle_and_feeds_the_functor(pcm, synth):
+    from oracle import Oracle
+    from oracle import loader as L
+    p, T, G = _corr_problem(synth)
+    o = Oracle("GICP", "LM", regularization="PCLOMP", max_corr_dist=0.6)
+    o.set_input_target(p.submap); o.set_input_source(p.scan)
+    g = pcm.GicpRegistration(0, regularization="PCLOMP", max_corr_dist=0.6)
+    g.set_input_target(p.submap); g.set_input_source(p.scan)
+    for Tk in (np.eye(4, dtype=np.float32), T):                                  # first outer iteration, and a later one
+        isrc0, itgt0, M0 = o.gicp_bfgs_correspondences(Tk, G)
+        m = g.gicp_bfgs_update_correspondences(Tk, G)
+        isrc1, itgt1, M1 = g.gicp_bfgs_get_correspondences()
+        assert m == len(isrc0) and np.array_equal(isrc1, isrc0)
+        same = itgt1 == itgt0                                                    # exact distance ties may pick another of two equidistant targets
+        assert same.mean() > 0.9995
+        assert np.abs(M1[same] - M0[same]).max() <= 1e-6 * np.abs(M0).max()
+        # the functor on the device-packed set == the oracle's functor on the oracle's set (cloud_src = guess * input, :479)
+        out = np.ones((len(p.scan), 4), np.float32)
+        Gd = G.astype(np.float32)
+        for a in range(3):
+            out[:, a] = Gd[a, 0] * p.scan[:, 0] + (Gd[a, 1] * p.scan[:, 1] + (Gd[a, 2] * p.scan[:, 2] + Gd[a, 3]))
+        maha = np.tile(np.eye(4, dtype=np.float32), (len(p.scan), 1, 1))
+        maha[isrc0, :3, :3] = M0
+        maha_cm = np.ascontiguousarray(maha.transpose(0, 2, 1)).reshape(-1, 16)
+        base = np.eye(4, dtype=np.float32)
+        x = np.array([0.01, -0.02, 0.005, 0.002, -0.001, 0.003])
+        tgt4 = np.ascontiguousarray(p.submap[:, :4], np.float32)
+        f0, g0 = L.gicp_bfgs_fdf(out, tgt4, isrc0, itgt0, maha_cm, base, x, 2)
+        f1, g1 = g.gicp_bfgs_fdf(base, x, 2)
+        assert abs(f1 - f0) <= 1e-6 * abs(f0) and np.abs(g1 - g0).max() <= 1e-6 * np.abs(g0).max()
