@@ -262,6 +262,11 @@ int pcm_ndt_score(pcm_ctx *ctx, const float T[16], double *score);
  * Replaces FastGICP::getSourceCovariances / getTargetCovariances
  * (fast_gicp/include/fast_gicp/gicp/fast_gicp.hpp:64-70; computed at impl/fast_gicp_impl.hpp:239-298). */
 int pcm_get_covariances(pcm_ctx *ctx, int target, double *out, size_t capacity_points, size_t *n);
+/* setSourceCovariances / setTargetCovariances (impl/fast_gicp_impl.hpp:93-100; pclomp gicp_omp.h:165,186): hand in the
+ * per-point covariances instead of having them computed -- n matrices of `elems` doubles (9 = 3x3, 16 = Matrix4d, its 3x3
+ * block is read), input order.  As in the reference they are used while their count equals the cloud's (:104-109), dropped by the
+ * next pcm_set_source / pcm_set_target (:78,89) and swapped by pcm_swap_source_and_target (:55).  GICP and VGICP models. */
+int pcm_set_covariances(pcm_ctx *ctx, int target, const double *covs, size_t n, int elems);
 
 /* common::Pose6D (jueying_lio/msg/Pose6D.msg): one propagated IMU pose of the frame (rot row-major) */
 typedef struct pcm_imu_pose {

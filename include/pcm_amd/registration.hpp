@@ -193,6 +193,15 @@ public:
     for (size_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) out[i](a, b) = raw[i * 9 + a * 3 + b];
     return out;
   }
+  void setCovariances(bool target, const std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>>& covs) {
+    this->push_config();
+    std::vector<double> raw(covs.size() * 9);
+    for (size_t i = 0; i < covs.size(); i++) for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) raw[i * 9 + a * 3 + b] = covs[i](a, b);
+    this->check(pcm_set_covariances(this->ctx_, target ? 1 : 0, raw.data(), covs.size(), 9), "pcm_set_covariances");
+  }
+  // setSourceCovariances / setTargetCovariances  fast_gicp.hpp:60-62 (Matrix4d, the 3x3 block is the covariance)
+  void setSourceCovariances(const std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>>& covs) { setCovariances(false, covs); }
+  void setTargetCovariances(const std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>>& covs) { setCovariances(true, covs); }
   std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>> getSourceCovariances() { return getCovariances(false); }
   std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>> getTargetCovariances() { return getCovariances(true); }
 };

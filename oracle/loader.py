@@ -171,6 +171,14 @@ class Oracle:
         lib().orc_obs_model(self._h, C.byref(st), int(extrinsic_est_en), int(converge), HTH.ctypes.data, HTh.ctypes.data, C.byref(n), C.byref(s2))
         return HTH, HTh, n.value, s2.value
 
+    def set_covariances(self, covs, target=False):
+        """setSourceCovariances / setTargetCovariances: (N,3,3) float64, input order."""
+        L = lib()
+        L.orc_set_covariances.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        a = np.ascontiguousarray(covs, np.float64).reshape(-1, 9)
+        if L.orc_set_covariances(self._h, int(bool(target)), a.ctypes.data, a.shape[0]) != 0:
+            raise RuntimeError("orc_set_covariances: size mismatch")
+
     def gicp_bfgs_correspondences(self, transformation, guess):
         """pclomp GICP correspondence step: (idx_src, idx_tgt, mahalanobis (m,3,3) float32) in source order."""
         L = lib()

@@ -538,3 +538,15 @@ int orc_gicp_bfgs_correspondences(void *h, const float transformation[16], const
   if (m_out) *m_out = m;
   return 0;
 }
+
+/* setSourceCovariances / setTargetCovariances  (impl/fast_gicp_impl.hpp:93-100): replace the per-point covariances (9 doubles each,
+ * row-major, input order); they stay until the cloud is set again. */
+int orc_set_covariances(void *h, int target, const double *cov9, long n) {
+  oracle *o = (oracle *)h;
+  orc_gicp_state *s = st(o);
+  orc_gicp_prepare(o);
+  if (n != (target ? o->tgt.n : o->src.n)) return -1;
+  memcpy(target ? s->tgt_cov : s->src_cov, cov9, sizeof(double) * 9 * (size_t)n);
+  if (target) s->vmap_valid = 0;   /* FastVGICP builds its voxel distributions from target_covs_ */
+  return 0;
+}

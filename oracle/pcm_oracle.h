@@ -103,6 +103,7 @@ void orc_gicp_bfgs_apply_state(const float base[16], const double x[6], float T[
 void orc_gicp_bfgs_r_derivative(const double x[6], const double R[9], double g[6]);
 int orc_gicp_bfgs_fdf(const float *src, const float *tgt, long stride_f, const int *idx_src, const int *idx_tgt, long m, const float *maha,
                       const float base[16], const double x[6], int mode, double *f_out, double g[6]);
+int orc_set_covariances(void *h, int target, const double *cov9, long n);   /* setSource/TargetCovariances  fast_gicp_impl.hpp:93-100 */
 /* the correspondence step of pclomp GICP's computeTransformation (gicp_omp_impl.hpp:405-472) on a GICP oracle; orc_gicp.c */
 int orc_gicp_bfgs_correspondences(void *h, const float transformation[16], const float guess[16], int *idx_src, int *idx_tgt, float *maha9, long *m_out);
 /* LaserMapping::ObsModel (jueying_lio/src/laser_mapping.cc:592-701) + the reduction the IEKF

@@ -874,6 +874,27 @@ __global__ void __launch_bounds__(256) k_fitness(TargetView tg, int coord_mode, 
   }
 }
 
+// setSourceCovariances / setTargetCovariances (fast_gicp_impl.hpp:93-100): the caller's matrices, input order -> map order
+__global__ void __launch_bounds__(256) k_scatter_cov(const uint32_t* __restrict__ order, const double* __restrict__ in6, uint32_t n, double* __restrict__ out6) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= n) return;
+  const double* s = in6 + (size_t)order[k] * 6;
+#pragma unroll
+  for (int a = 0; a < 6; a++) out6[(size_t)k * 6 + a] = s[a];
+}
+int upload_covariances(hipStream_t stream, const TargetMap& map, const double* h_cov6, double* d_cov, std::string* err) {
+  const uint32_t n = map.num_points;
+  if (n == 0) return PCM_OK;
+  double* tmp = nullptr;
+  hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&tmp), sizeof(double) * 6 * (size_t)n, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp, h_cov6, sizeof(double) * 6 * (size_t)n, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) { k_scatter_cov<<<(n + 255u) / 256u, 256, 0, stream>>>(map.order, tmp, n, d_cov); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);   // h_cov6 is the caller's
+  if (tmp) (void)hipFreeAsync(tmp, stream);
+  if (e != hipSuccess) { *err = std::string("upload_covariances: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return PCM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // pclomp GICP-BFGS, correspondence step of computeTransformation (ndt_omp/include/pclomp/gicp_omp_impl.hpp:405-462): for every
 // source point i -- output[i] = guess * input[i] (pcl::transformPointCloud, float), query = transformation_ * output[i] (float

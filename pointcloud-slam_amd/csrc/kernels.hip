@@ -589,9 +589,11 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
                 const float4 nx = *reinterpret_cast<const float4*>(pbase + off + 16);
                 if (STATS) n_cand++;
                 best_offer(best, mp, q, off, kp.max_range_sq);
-                if (__float_as_int(nx.w) < 0) break;   // the next staged point opens another voxel (or is the sentinel)
+                // advance first, then leave: written the other way round the compiler keeps `mp` and `off` of the lanes that
+                // leave with four selects and a second compare per trip, although nobody reads them after the loop
                 mp = nx;
                 off += 16;
+                if (__float_as_int(nx.w) < 0) break;   // the staged point just fetched opens another voxel (or is the sentinel)
               }
             }
           }

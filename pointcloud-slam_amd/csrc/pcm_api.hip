@@ -265,7 +265,10 @@ int prepare(pcm_ctx* c) {
         c->tgt_cov_cap = c->map.num_points;
       }
       const int reg_code = c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0);   // + 16: float CUDA-core semantics
-      int rc = compute_covariances(c->stream, c->map, c->cfg.k_correspondences, reg_code, c->tgt_cov, &c->err);
+      // `if (target_covs_.size() != target_->size()) calculate_covariances(...)`  fast_gicp_impl.hpp:107-109
+      const bool given = c->cfg.model != PCM_MODEL_VGICP_CUDA && c->user_cov[1].size() == (size_t)c->map.num_points * 6 && c->map.num_points == c->tgt.n;
+      int rc = given ? upload_covariances(c->stream, c->map, c->user_cov[1].data(), c->tgt_cov, &c->err)
+                     : compute_covariances(c->stream, c->map, c->cfg.k_correspondences, reg_code, c->tgt_cov, &c->err);
       if (rc != PCM_OK) return rc;
       if (c->cfg.model == PCM_MODEL_VGICP_CUDA) {
         if (c->cvox_cap < c->map.num_voxels) {
@@ -296,7 +299,9 @@ int prepare(pcm_ctx* c) {
         HIPCK(c, hipMalloc(&c->src_cov, sizeof(double) * 6 * (size_t)c->srcmap.num_points));
         c->src_cov_cap = c->srcmap.num_points;
       }
-      int rc = compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0), c->src_cov, &c->err);
+      const bool given = c->cfg.model != PCM_MODEL_VGICP_CUDA && c->user_cov[0].size() == (size_t)c->srcmap.num_points * 6 && c->srcmap.num_points == c->src.n;   // :104-106
+      int rc = given ? upload_covariances(c->stream, c->srcmap, c->user_cov[0].data(), c->src_cov, &c->err)
+                     : compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0), c->src_cov, &c->err);
       if (rc != PCM_OK) return rc;
       c->src_cov_valid = true;
     }
@@ -502,7 +507,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   // status byte of a pair says "done" the next queued pair takes its place in the list (it was initialised with the others and
   // simply never launched before).  Every round then carries about `window` live pairs, so the fixed cost of a round (two launches,
   // their boundaries) is shared by that many registrations for the whole batch, not only in its first rounds.  No device-side hand-off.
-  const bool host_window = window < n && n <= 256 && window <= 64;
+  const bool host_window = window < n && n <= 256 && window <= kMaxListedPairs;
   const int max_rounds = host_window ? per_pair_rounds * ((n + window - 1) / window + 1) + 4
                                      : per_pair_rounds * (n - window + 1) + 1 + 2 * (n - window);   // + the rounds a handed-over pair spends PENDING
   const size_t per_pair_partials = (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride;
@@ -548,9 +553,9 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   int rounds_done = 0;
   size_t prof_used = 0;
   // Only the pairs the host still believes active are launched (the list rides in the kernel arguments, batches of
-  // <= 64 pairs): an early-exit workgroup is not free, and the late rounds of a batch have one or two live pairs.
+  // <= kMaxListedPairs pairs): an early-exit workgroup is not free, and the late rounds of a batch have one or two live pairs.
   // The list lags one round (the status bytes are read one round behind); a stale entry exits at once.
-  const bool use_list = (n <= 64 && window == n) || host_window;
+  const bool use_list = (n <= kMaxListedPairs && window == n) || host_window;
   std::vector<uint8_t> act((size_t)(host_window ? window : n));
   for (size_t i = 0; i < act.size(); i++) act[i] = (uint8_t)i;
   int next_queued = host_window ? window : n;   // host window: first pair that has not been launched yet
@@ -998,6 +1003,7 @@ int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   CHECK_CTX(c);
   if (tag != 0 && tag == c->tgt.tag && c->tgt.n == n) return PCM_OK;  // `if (target_ == cloud) return;`  fast_gicp_impl.hpp:83-85
   int rc = set_cloud(c, &c->tgt, points, n, stride_bytes, memory, tag, false);
+  c->user_cov[1].clear();   // target_covs_.clear()  fast_gicp_impl.hpp:89
   c->map.valid = false;
   c->next_seq = (uint32_t)n;
   c->lio_planes_valid = false;
@@ -1029,6 +1035,7 @@ int pcm_set_source(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   CHECK_CTX(c);
   if (tag != 0 && tag == c->src.tag && c->src.n == n) return PCM_OK;  // fast_gicp_impl.hpp:72-74
   int rc = set_cloud(c, &c->src, points, n, stride_bytes, memory, tag, true);
+  c->user_cov[0].clear();   // source_covs_.clear()  fast_gicp_impl.hpp:78
   c->src_sorted = false;
   c->lio_planes_valid = false;
   c->srcmap.valid = false;
@@ -1040,6 +1047,7 @@ int pcm_swap_source_and_target(pcm_ctx* c) {
   CHECK_CTX(c);
   HIPCK(c, hipStreamSynchronize(c->stream));
   std::swap(c->src, c->tgt);
+  std::swap(c->user_cov[0], c->user_cov[1]);   // source_covs_.swap(target_covs_)  fast_gicp_impl.hpp:55
   c->map.valid = false;
   c->srcmap.valid = false;
   c->src_sorted = false;
@@ -1332,6 +1340,24 @@ int pcm_voxel_downsample(pcm_ctx* c, const void* points, size_t n, size_t stride
     HIPCK(c, hipMemcpyAsync(out, dst, *n_out * stride, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
   }
+  return PCM_OK;
+}
+
+// setSourceCovariances / setTargetCovariances  fast_gicp_impl.hpp:93-100: `covs` = n matrices of `elems` doubles each (9: 3x3, 16: the
+// reference's Matrix4d -- its top-left 3x3 block; symmetric, so row- and column-major read the same), input order
+int pcm_set_covariances(pcm_ctx* c, int target, const double* covs, size_t n, int elems) {
+  CHECK_CTX(c);
+  if ((!covs && n) || (elems != 9 && elems != 16)) return PCM_ERR_INVALID_ARGUMENT;
+  if (!is_gicp(c->cfg.model) || c->cfg.model == PCM_MODEL_VGICP_CUDA) { c->err = "covariances can be set for the GICP / VGICP models"; return PCM_ERR_UNSUPPORTED; }
+  std::vector<double>& u = c->user_cov[target ? 1 : 0];
+  u.resize(n * 6);
+  const int ld = elems == 9 ? 3 : 4;
+  for (size_t i = 0; i < n; i++) {
+    const double* m = covs + i * (size_t)elems;
+    double* o = &u[i * 6];
+    o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[ld + 1]; o[4] = m[ld + 2]; o[5] = m[2 * ld + 2];
+  }
+  if (target) c->tgt_cov_valid = false; else c->src_cov_valid = false;
   return PCM_OK;
 }
 

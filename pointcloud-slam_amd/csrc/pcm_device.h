@@ -225,6 +225,8 @@ constexpr int kPartialStride = 32;  // doubles per block partial (padded)
 constexpr int kLioSums = 92;        // 78 (HTH upper) + 12 (H^T h) + sum h^2 + count
 constexpr int kLioStride = 96;
 
+constexpr int kMaxListedPairs = 128;
+
 struct KernelParams {
   int32_t num_neighbors;
   int32_t knn;
@@ -245,7 +247,7 @@ struct KernelParams {
   int32_t lin_points_per_block;  // source elements per workgroup of the linearize kernel (256 for k_linearize tiles)
   int32_t coord_mode;         // CoordMode of the target map (GICP / VGICP kernels)
   int32_t use_list;           // 1: the grid's pair axis indexes `active` (only pairs the host still believes active are launched)
-  uint8_t active[64];         // pair index of each grid entry (batches of <= 64 pairs)
+  uint8_t active[kMaxListedPairs];   // pair index of each grid entry (batches of <= kMaxListedPairs pairs; indices < 256)
   double max_corr_sq;         // GICP: corr_dist_threshold_^2 (double, as pcl::Registration holds it)
 };
 

@@ -85,6 +85,7 @@ constexpr int kGicpBfgsMaxBlocks = 512;   // rows of the partial-sum table
 size_t gicp_bfgs_scratch_bytes(size_t m);
 int gicp_bfgs_pack_device(hipStream_t stream, const void* d_src, const void* d_tgt, size_t stride, const int* d_idx_src, const int* d_idx_tgt, const float* d_maha, size_t m,
                           void* d_records, std::string* err);
+int upload_covariances(hipStream_t stream, const TargetMap& map, const double* h_cov6, double* d_cov, std::string* err);   // input-order 6-double rows -> map order
 // correspondence step of pclomp GICP-BFGS on the device (gicp.hip): packs the functor's records in source order, returns their number
 int gicp_bfgs_correspond_device(hipStream_t stream, const TargetMap& tmap, int coord_mode, const TargetMap& smap, const double* src_cov, const double* tgt_cov,
                                 const float* guess, const float* transformation, double max_corr_dist, float4* d_records, int32_t* d_idx_src, int32_t* d_idx_tgt, uint32_t* m_out,
@@ -180,6 +181,7 @@ struct pcm_ctx {
   size_t pre_arena_cap = 0;
   char* bfgs = nullptr;        // GICP-BFGS functor: packed correspondence records + partial sums (gicp_bfgs.hip)
   size_t bfgs_cap = 0, bfgs_m = 0;
+  std::vector<double> user_cov[2];   // [0] source, [1] target: covariances handed in by the caller (6 per point, input order); empty = compute
   int32_t* bfgs_idx = nullptr; // [2][bfgs_idx_cap] source / target index of every packed pair (device-side correspondence step)
   size_t bfgs_idx_cap = 0;
   double* bfgs_host = nullptr; // pinned, device-visible: the 14 sums land here without a copy command

@@ -208,6 +208,12 @@ class Registration:
             self._check(self._L.pcm_get_covariances(self._h, int(bool(target)), out.ctypes.data, n.value, C.byref(n)))
         return out
 
+    def set_covariances(self, covs, target: bool = False):
+        """setSourceCovariances / setTargetCovariances (fast_gicp_impl.hpp:93-100): (N,3,3) or (N,4,4) float64, input order."""
+        a = np.ascontiguousarray(covs, np.float64)
+        elems = a.shape[1] * a.shape[2]
+        self._check(self._L.pcm_set_covariances(self._h, int(bool(target)), a.ctypes.data, a.shape[0], elems))
+
     def set_correspondence_randomness(self, k): self._set(k_correspondences=int(k))   # setCorrespondenceRandomness  fast_gicp_impl.hpp:61-63
     def set_regularization_method(self, m): self._set(regularization=m)               # setRegularizationMethod      :66-68
 

@@ -39,7 +39,7 @@ int main() {
   auto src = std::make_shared<Cloud>(); auto tgt = std::make_shared<Cloud>();
   double s = 0;
   { pcm_amd::P2PlaneRegistration<P, P> r; r.setNumNeighborCells(27); r.setMaxRange(5.0); r.setOptimizer(pcm_amd::LSQ_OPTIMIZER_TYPE::GaussNewton); r.setInitialLambdaFactor(1e-9); r.setDebugPrint(false); s += common_surface(r, src, tgt); }
-  { pcm_amd::GicpRegistration<P, P> r; r.setCorrespondenceRandomness(20); r.setRegularizationMethod(pcm_amd::RegularizationMethod::PLANE); s += common_surface(r, src, tgt); s += r.getSourceCovariances().size() + r.getTargetCovariances().size(); }
+  { pcm_amd::GicpRegistration<P, P> r; r.setCorrespondenceRandomness(20); r.setRegularizationMethod(pcm_amd::RegularizationMethod::PLANE); s += common_surface(r, src, tgt); s += r.getSourceCovariances().size() + r.getTargetCovariances().size(); r.setSourceCovariances(r.getSourceCovariances()); r.setTargetCovariances(r.getTargetCovariances()); }
   { pcm_amd::VgicpRegistration<P, P> r; r.setResolution(1.0); r.setNeighborSearchMethod(pcm_amd::NeighborSearchMethod::DIRECT7); r.setVoxelAccumulationMode(pcm_amd::VoxelAccumulationMode::ADDITIVE); s += common_surface(r, src, tgt); }
   { pcm_amd::NdtRegistration<P, P> r; r.setDistanceMode(pcm_amd::NDTDistanceMode::D2D); r.setNeighborSearchMethod(pcm_amd::NeighborSearchMethod::DIRECT7, -1.0); s += common_surface(r, src, tgt); }
   { pcm_amd::VgicpCudaRegistration<P, P> r; r.setResolution(1.0); r.setCorrespondenceRandomness(20); r.setNeighborSearchMethod(pcm_amd::NeighborSearchMethod::DIRECT_RADIUS, 1.5); s += common_surface(r, src, tgt); }

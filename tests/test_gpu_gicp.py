@@ -199,3 +199,40 @@ def test_cuda_full_align_on_a_dense_pair(pcm, synth):
         dt, dr = pose_error(result_T(ro), rg.T64)
         assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (optimizer, nn, dt, dr)
         assert rg.iterations == ro.iterations and rg.converged == bool(ro.converged)
+
+
+@pytest.mark.parametrize("model", ["GICP", "VGICP"])
+def test_covariances_handed_in_by_the_caller(pcm, pair, model):
+    """setSourceCovariances / setTargetCovariances (fast_gicp_impl.hpp:93-110): used while their count equals the cloud's, dropped by
+    the next setInputSource / setInputTarget.  The caller's matrices here are the computed ones deformed, so the result must differ
+    from the default and equal the oracle's with the same matrices."""
+    from oracle import Oracle
+    from oracle.loader import result_T
+    p = pair
+    kw = dict(voxel_resolution=1.0, num_neighbors=7) if model == "VGICP" else {}
+    g = (pcm.VgicpRegistration if model == "VGICP" else pcm.GicpRegistration)(0, optimizer="LM", **kw)
+    cfg = g.config
+    o = Oracle(model, "LM", voxel_resolution=cfg.voxel_resolution, num_neighbors=cfg.num_neighbors, k_correspondences=cfg.k_correspondences,
+               regularization=cfg.regularization, max_iterations=cfg.max_iterations)
+    for r in (o, g):
+        r.set_input_target(p.submap); r.set_input_source(p.scan)
+    T = p.guess.astype(np.float64)
+    c_def, H_def, b_def, _ = g.evaluate_cost(T)
+    cs, ct = g.get_covariances(False), g.get_covariances(True)
+    D = np.diag([1.0, 2.0, 0.5])
+    cs2 = D @ cs @ D.T + 0.01 * np.eye(3)
+    ct2 = 1.5 * ct + 0.02 * np.eye(3)
+    g.set_covariances(cs2, False); g.set_covariances(ct2, True)
+    o.set_covariances(cs2, False); o.set_covariances(ct2, True)
+    assert np.allclose(g.get_covariances(False), cs2, rtol=0, atol=0) and np.allclose(g.get_covariances(True), ct2, rtol=0, atol=0)
+    c0, H0, b0 = o.linearize(T)
+    c1, H1, b1, inl = g.evaluate_cost(T)
+    assert inl == o.num_inliers and rel_err(H1, H0) < 1e-9 and rel_err(b1, b0) < 1e-9 and abs(c1 - c0) <= 1e-9 * abs(c0)
+    assert abs(c1 - c_def) > 1e-3 * abs(c_def)                      # the caller's matrices really were used
+    ro, rg = o.align(p.guess), g.align(p.guess)
+    dt, dr = pose_error(result_T(ro), rg.T64)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+    g.set_input_source(p.scan.copy())                                # a new cloud: source_covs_.clear()  :78
+    assert np.abs(g.get_covariances(False) - cs).max() <= 1e-12 * np.abs(cs).max()
+    with pytest.raises(pcm.PcmError):
+        pcm.VgicpCudaRegistration(0).set_covariances(cs2, False)
