@@ -104,7 +104,7 @@ def full_size_parity(gpu_results, oracle_results):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs-per-gpu", type=int, default=64, help="registrations per step and GPU (one batch = one step)")
     ap.add_argument("--pipeline", type=int, default=2,
