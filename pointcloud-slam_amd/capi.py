@@ -17,6 +17,7 @@ SYMBOLS = [
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
+PCM_ABI_VERSION = 2   # include/pcm_amd.h
 PCM_OK = 0
 PCM_FLAG_NO_LDS_STAGING = 1
 PCM_FLAG_FUSED_STEP = 2
