@@ -346,7 +346,7 @@ __device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* 
 
 // one object, the parameters in the kernel arguments (pcm_ndt_derivatives, the host-driven solver)
 template <bool HESS>
-__global__ void __launch_bounds__(256) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+__global__ void __launch_bounds__(256, 2) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
                                                             double* __restrict__ partials) {
   pclndt_derivatives_body<HESS>(tg, leaves, src, n, per, P, partials);
 }
@@ -362,7 +362,9 @@ __global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const Pcl
 // convergence test -- so the host takes no decision between evaluations (it reads one status byte per object, a round behind).
 // grid = (max workgroups of an object, objects)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pclndt_batch_pass(const NdtObject* __restrict__ objs, const ndtomp::NdtMachine* __restrict__ ms) {
+// two workgroups per CU: the float-Hessian body wants 274 registers, which leaves ONE wave per SIMD; capped at 255 (19 spilled
+// dwords) two waves hide each other's leaf loads: 1 593 -> 2 069 registrations/s at config 4 (three waves at 168: 1 287, the spills win)
+__global__ void __launch_bounds__(256, 2) k_pclndt_batch_pass(const NdtObject* __restrict__ objs, const ndtomp::NdtMachine* __restrict__ ms) {
   const NdtObject ob = objs[blockIdx.y];
   const int req = ms[blockIdx.y].request;
   if (req < 0 || blockIdx.x >= (uint32_t)ob.nblocks) return;
