@@ -84,7 +84,7 @@ __device__ inline double wave_sum_d(double v) {
 // grid = (blocks_per_pair, npairs), block = 256, kp.lin_points_per_block elements per workgroup
 // ---------------------------------------------------------------------------
 template <int KIND, bool TRIAL>   // KIND 0: NDT P2D, 1: NDT D2D, 2: VGICP of the CUDA core (compute_derivatives.cu:49-92)
-__global__ void __launch_bounds__(256) k_ndt(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
+__global__ void __launch_bounds__(256, 3) k_ndt(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp) {
   const int pair = PCM_PAIR_OF(kp, blockIdx.y);
   const int mode = states[pair].mode;
   if (mode != (TRIAL ? MODE_TRIAL : MODE_LINEARIZE)) return;

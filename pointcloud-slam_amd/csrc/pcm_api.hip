@@ -55,6 +55,26 @@ struct Workspace {
   std::vector<hipEvent_t> ev_prof;
 };
 
+// Spin until a round's status byte (mapped pinned host memory, stored by the step kernel) is non-zero.  On both error returns
+// the queued kernels may still be writing into the workspace and the flags: the stream is drained first, so that the caller can
+// destroy the context safely.  The runtime is asked (hipStreamQuery: has the stream died?) only after a wait far beyond any
+// round -- a query takes the locks the other slots' launches need; polled every few microseconds by several waiting threads it
+// throttled every launch of the process.
+int wait_status_byte(pcm_ctx* c0, hipStream_t st, volatile unsigned char* p, std::chrono::steady_clock::time_point t_start) {
+  unsigned spins = 0;
+  auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);
+  while (*p == 0) {
+    if ((++spins & 0xfff) != 0) continue;
+    const auto now = std::chrono::steady_clock::now();
+    if (now - t_start > std::chrono::seconds(20)) { (void)hipStreamSynchronize(st); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
+    if (now >= next_query) {
+      next_query = now + std::chrono::milliseconds(5);
+      if (hipStreamQuery(st) == hipSuccess && *p == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
+    }
+  }
+  return PCM_OK;
+}
+
 // The workspace belongs to the first context of a batch (contexts are single-threaded
 // objects), so independent batches may run concurrently from different host threads
 // on their own streams -- e.g. the stragglers of one batch under the bulk of the next.
@@ -607,22 +627,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
       const int np = use_list ? (int)prev_list.size() : n;
       for (int k = 0; k < np; k++) {
         const int i = use_list ? (int)prev_list[(size_t)k] : k;
-        unsigned spins = 0;
-        auto next_query = t_start + std::chrono::milliseconds(5);
-        while (row[i] == 0) {   // the round's status byte of pair i has not landed yet
-          if ((++spins & 0xfff) == 0) {
-            // on both error returns the queued kernels may still be writing into the workspace and h_flags: drain the stream
-            // first, so that the caller can destroy the context safely
-            const auto now = std::chrono::steady_clock::now();
-            if (now - t_start > std::chrono::seconds(20)) { (void)hipStreamSynchronize(st); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
-            // the runtime is asked only after a wait far beyond any round (a query takes the locks the other slots' launches
-            // need: polled every few microseconds by several waiting threads it throttled every launch of the process)
-            if (now >= next_query) {
-              next_query = now + std::chrono::milliseconds(5);
-              if (hipStreamQuery(st) == hipSuccess && row[i] == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
-            }
-          }
-        }
+        if (int wrc = wait_status_byte(c0, st, row + i, t_start)) return wrc;
         any_active |= row[i] == 1;
         if (row[i] == 1 && use_list) alive.push_back((uint8_t)i);
       }
@@ -826,19 +831,8 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
       volatile unsigned char* row = w.h_flags + (size_t)(r - 1) * n;
       bool any_active = false;
       const auto t_start = std::chrono::steady_clock::now();
-      auto next_query = t_start + std::chrono::milliseconds(5);
       for (int i = 0; i < n; i++) {
-        unsigned spins = 0;
-        while (row[i] == 0) {
-          if ((++spins & 0xfff) == 0) {
-            const auto now = std::chrono::steady_clock::now();
-            if (now - t_start > std::chrono::seconds(20)) { (void)hipStreamSynchronize(st); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
-            if (now >= next_query) {
-              next_query = now + std::chrono::milliseconds(5);
-              if (hipStreamQuery(st) == hipSuccess && row[i] == 0) { c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
-            }
-          }
-        }
+        if (int wrc = wait_status_byte(c0, st, row + i, t_start)) return wrc;
         any_active |= row[i] == 1;
       }
       if (!any_active) break;
