@@ -283,15 +283,16 @@ __global__ void __launch_bounds__(256) k_finish_round(const PairDesc* __restrict
     const int j = threadIdx.x & 31, g8 = threadIdx.x >> 5;
     double v[4] = {0.0, 0.0, 0.0, 0.0};
     // canonical partition: group r (0..31) = rows r, r + 32, r + 64, ...; thread (g8, j) sums groups r = g8 + 8q, q = 0..3, each in
-    // row order.  The four groups advance together, 16 independent loads in flight per trip (a 100k-point scan has 391 rows: 4
+    // row order.  The four groups advance together, 32 independent loads in flight per trip (a 100k-point scan has 391 rows: 2
     // trips to memory instead of 16); a row past the end is skipped, not added as zero (-0.0 + 0.0 would lose the sign)
     if (j < kNumSums) {
-      for (int b0 = 0; b0 < nblocks; b0 += 128) {
-        double x[4][4];
+      constexpr int kRowsPerTrip = 8;   // rows of each of the thread's four groups fetched together: 32 loads in flight
+      for (int b0 = 0; b0 < nblocks; b0 += 32 * kRowsPerTrip) {
+        double x[4][kRowsPerTrip];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < kRowsPerTrip; k++) {
             const int b = b0 + g8 + 8 * q + 32 * k;
             x[q][k] = b < nblocks ? gload_d(d.partials + (size_t)b * kPartialStride + j) : 0.0;
           }
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256) k_finish_round(const PairDesc* __restrict
 #pragma unroll
         for (int q = 0; q < 4; q++) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < kRowsPerTrip; k++) {
             const int b = b0 + g8 + 8 * q + 32 * k;
             if (b < nblocks) v[q] += x[q][k];
           }
