@@ -823,22 +823,66 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   hipStream_t st = c0->stream;
   HIPCK(c0, hipMemcpyAsync(w.d_objs, w.h_objs, sizeof(NdtObject) * n, hipMemcpyHostToDevice, st));
   HIPCK(c0, hipMemcpyAsync(w.d_ms, w.h_ms, sizeof(ndtomp::NdtMachine) * n, hipMemcpyHostToDevice, st));
-  int rounds = 0;
-  for (int r = 0; r < max_rounds; r++) {
-    launch_pclndt_batch_round(st, w.d_objs, w.d_ms, n, max_blocks, w.d_flags + (size_t)r * n);
-    rounds = r + 1;
-    if (r >= 1) {   // look one round behind, so that the next round is queued before the host knows whether it is needed
-      volatile unsigned char* row = w.h_flags + (size_t)(r - 1) * n;
-      bool any_active = false;
-      const auto t_start = std::chrono::steady_clock::now();
-      for (int i = 0; i < n; i++) {
-        if (int wrc = wait_status_byte(c0, st, row + i, t_start)) return wrc;
-        any_active |= row[i] == 1;
+  HIPCK(c0, hipStreamSynchronize(st));   // the groups below run on their own streams
+  // The objects advance in up to four groups, each in lock-step on the stream of its first object: registrations need 6 ... 37
+  // Newton iterations on the same map, and a single lock-step batch runs every round at the pace of its largest kernel while most
+  // objects have finished.  At most two rounds of a group are in flight (the host confirms a round's status bytes before it queues
+  // the one after the next); a group whose objects have all finished sees that one round late and stops.
+  struct Group { int lo, hi, max_blocks, launched, confirmed; bool done; hipStream_t st; };
+  // Measured at config 4 (100k-point scans): 8 objects -- four groups of two 1 081 registrations/s, one group 898; 32 objects -- four
+  // groups 1 814, one group 2 058: with the device already full a split only adds launches, so it is made for small batches only.
+  size_t total_points = 0;
+  for (int i = 0; i < n; i++) total_points += ctxs[i]->src.n;
+  const int ngroups = total_points <= 1600000 ? std::min(n, 4) : 1;
+  std::vector<Group> groups((size_t)ngroups);
+  for (int g = 0; g < ngroups; g++) {
+    Group& G = groups[(size_t)g];
+    G.lo = (int)((long long)n * g / ngroups); G.hi = (int)((long long)n * (g + 1) / ngroups);
+    G.launched = 0; G.confirmed = 0; G.done = false; G.st = ctxs[G.lo]->stream; G.max_blocks = 1;
+    for (int i = G.lo; i < G.hi; i++) G.max_blocks = std::max(G.max_blocks, (int)w.h_objs[i].nblocks);
+  }
+  const auto t_start = std::chrono::steady_clock::now();
+  auto next_query = t_start + std::chrono::milliseconds(5);
+  int live = ngroups;
+  unsigned idle_spins = 0;
+  while (live > 0) {
+    bool progress = false;
+    for (Group& G : groups) {
+      if (G.done) continue;
+      if (G.confirmed < G.launched) {   // status bytes of the oldest unconfirmed round of this group: all landed?
+        volatile unsigned char* row = w.h_flags + (size_t)G.confirmed * n;
+        bool ready = true, any_active = false;
+        for (int i = G.lo; i < G.hi; i++) { const unsigned char f = row[i]; ready &= f != 0; any_active |= f == 1; }
+        if (ready) {
+          G.confirmed++;
+          progress = true;
+          if (!any_active || G.confirmed >= max_rounds) { G.done = true; live--; continue; }
+        }
       }
-      if (!any_active) break;
+      if (G.launched - G.confirmed < 2 && G.launched < max_rounds) {
+        launch_pclndt_batch_round(G.st, w.d_objs + G.lo, w.d_ms + G.lo, G.hi - G.lo, G.max_blocks, w.d_flags + (size_t)G.launched * n + G.lo);
+        G.launched++;
+        progress = true;
+      }
+    }
+    if (progress) { idle_spins = 0; continue; }
+    if ((++idle_spins & 0xfff) != 0) continue;
+    const auto now = std::chrono::steady_clock::now();
+    auto drain = [&]() { for (Group& G : groups) (void)hipStreamSynchronize(G.st); };
+    if (now - t_start > std::chrono::seconds(20)) { drain(); c0->err = "timeout waiting for the GPU round status"; return PCM_ERR_HIP; }
+    if (now >= next_query) {   // a dead stream never writes its status bytes (see wait_status_byte for why this is asked rarely)
+      next_query = now + std::chrono::milliseconds(5);
+      for (Group& G : groups)
+        if (!G.done && G.confirmed < G.launched && hipStreamQuery(G.st) == hipSuccess) {
+          volatile unsigned char* row = w.h_flags + (size_t)G.confirmed * n;
+          bool ready = true;
+          for (int i = G.lo; i < G.hi; i++) ready &= row[i] != 0;
+          if (!ready) { drain(); c0->err = "stream drained without a round status (kernel fault?)"; return PCM_ERR_HIP; }
+        }
     }
   }
   HIPCK(c0, hipGetLastError());
+  for (Group& G : groups) HIPCK(c0, hipStreamSynchronize(G.st));
   HIPCK(c0, hipMemcpyAsync(w.h_ms, w.d_ms, sizeof(ndtomp::NdtMachine) * n, hipMemcpyDeviceToHost, st));
   HIPCK(c0, hipStreamSynchronize(st));
   int worst = PCM_OK;
@@ -858,7 +902,6 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
     ctxs[i]->stats.linearize_launches += (uint64_t)(m.n_deriv + m.n_hess);
     ctxs[i]->stats.point_passes += (uint64_t)(m.n_deriv + m.n_hess) * ctxs[i]->src.n;
   }
-  (void)rounds;
   return worst;
 }
 
