@@ -830,10 +830,11 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   // the one after the next); a group whose objects have all finished sees that one round late and stops.
   struct Group { int lo, hi, max_blocks, launched, confirmed; bool done; hipStream_t st; };
   // Measured at config 4 (100k-point scans): 8 objects -- four groups of two 1 081 registrations/s, one group 898; 32 objects -- four
-  // groups 1 814, one group 2 058: with the device already full a split only adds launches, so it is made for small batches only.
+  // groups 1 814, one group 2 058; 16 objects -- four groups 897, one group 1 406: with the device busy a split only adds launches and
+  // host-side waiting, so it is made for small batches only.
   size_t total_points = 0;
   for (int i = 0; i < n; i++) total_points += ctxs[i]->src.n;
-  const int ngroups = total_points <= 1600000 ? std::min(n, 4) : 1;
+  const int ngroups = total_points <= 1000000 ? std::min(n, 4) : 1;
   std::vector<Group> groups((size_t)ngroups);
   for (int g = 0; g < ngroups; g++) {
     Group& G = groups[(size_t)g];
