@@ -286,6 +286,14 @@ int pcm_undistort(pcm_ctx *ctx, void *points, size_t n, size_t stride_bytes, siz
  * Replaces voxel_scan_.filter() of LaserMapping::Run (jueying_lio/src/laser_mapping.cc:323-328). */
 int pcm_voxel_downsample(pcm_ctx *ctx, const void *points, size_t n, size_t stride_bytes, int memory, float leaf_size, void *out, size_t capacity_points, size_t *n_out);
 
+/* PointCloudPreprocess::AviaHandler (jueying_lio/src/pointcloud_preprocess.cc:44-88): the n points of a livox_ros_driver::CustomMsg
+ * (20-byte records {uint32 offset_time; float x, y, z; uint8 reflectivity, tag, line; pad} -- msg->points.data()) filtered by line, tag,
+ * point_filter_num, the duplicate test against the previous copied point and the blind radius, with the reference's own operator
+ * precedence; the kept points leave in input order as pcl::PointXYZINormal records (48 bytes: x y z 1, 0 0 0 0, intensity, curvature
+ * = offset_time / 1e6 [ms], 0 0).  `out` must hold n records; *n_out = kept points. */
+int pcm_livox_filter(pcm_ctx *ctx, const void *custom_points, size_t n, int memory, int num_scans, int point_filter_num, double blind, void *out, size_t capacity_points,
+                     size_t *n_out);
+
 /* pclomp GICP-BFGS (jueying_slam's GICP_OMP option): the functor its BFGS minimises, evaluated on the device.
  * set_correspondences packs the outer iteration's correspondence set once -- tmp_src_/tmp_tgt_ (records of
  * stride_bytes, x y z first), tmp_idx_src_/tmp_idx_tgt_ (m indices, in range: checked for host memory only) and

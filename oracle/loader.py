@@ -346,3 +346,17 @@ def gicp_bfgs_apply_state(base_T, x):
     L.orc_gicp_bfgs_apply_state.restype = None
     L.orc_gicp_bfgs_apply_state(base.ctypes.data, xx.ctypes.data, T.ctypes.data)
     return T.reshape(4, 4)
+
+
+LIVOX_POINT = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1"), ("pad", "u1")])
+
+
+def livox_filter(msg_points, num_scans=6, point_filter_num=1, blind=0.01):
+    """PointCloudPreprocess::AviaHandler: structured array of LIVOX_POINT -> (m, 12) float32 PointXYZINormal records."""
+    L = lib()
+    L.orc_livox_filter.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    L.orc_livox_filter.restype = C.c_long
+    a = np.ascontiguousarray(msg_points, dtype=LIVOX_POINT)
+    out = np.zeros((max(len(a), 1), 12), np.float32)
+    m = L.orc_livox_filter(a.ctypes.data, len(a), int(num_scans), int(point_filter_num), float(blind), out.ctypes.data)
+    return out[:m].copy()

@@ -118,3 +118,37 @@ long orc_voxel_downsample(const float *pts, long n, long stride_floats, float le
   free(acc); free(it);
   return nout;
 }
+
+/* PointCloudPreprocess::AviaHandler  (jueying_lio/src/pointcloud_preprocess.cc:44-88): livox CustomMsg points -> the PointXYZINormal
+ * cloud the matcher receives.  `msg` holds n records of 20 bytes {uint32 offset_time; float x, y, z; uint8 reflectivity, tag, line; pad}
+ * (livox_ros_driver/msg/CustomPoint.msg as the generated C++ struct lays it out).  A point i >= 1 is copied into cloud_full_[i] when
+ * its line and tag pass and i % point_filter_num == 0 (:58-67), and kept when it differs from cloud_full_[i - 1] -- which is the
+ * previous raw point if THAT one was copied, else the zero point the resize() left (:50; the reference's loop is par_unseq: this
+ * is its serial reading) -- under the reference's own precedence: |dx| > 1e-7 || |dy| > 1e-7 || (|dz| > 1e-7 && r^2 > blind^2)
+ * (:69-74).  out: 12 floats per kept point {x, y, z, 1, 0, 0, 0, 0, intensity, curvature, 0, 0} (pcl::PointXYZINormal), input order. */
+long orc_livox_filter(const unsigned char *msg, long n, int num_scans, int point_filter_num, double blind, float *out) {
+  long m = 0;
+  for (long i = 1; i < n; i++) {
+    const unsigned char *r = msg + 20 * i, *rp = msg + 20 * (i - 1);
+    unsigned int ot; float xyz[3], pxyz[3] = {0.f, 0.f, 0.f};
+    memcpy(&ot, r, 4); memcpy(xyz, r + 4, 12);
+    const unsigned char refl = r[16], tag = r[17], line = r[18];
+    if (!((int)line < num_scans && ((tag & 0x30) == 0x10 || (tag & 0x30) == 0x00))) continue;
+    if (i % point_filter_num != 0) continue;
+    if (i - 1 >= 1) {   /* was point i - 1 copied into cloud_full_?  (index 0 never is: the loop starts at 1) */
+      const unsigned char ptag = rp[17], pline = rp[18];
+      if ((int)pline < num_scans && ((ptag & 0x30) == 0x10 || (ptag & 0x30) == 0x00) && (i - 1) % point_filter_num == 0) memcpy(pxyz, rp + 4, 12);
+    }
+    const float r2 = xyz[0] * xyz[0] + xyz[1] * xyz[1] + xyz[2] * xyz[2];
+    const int keep = ((double)fabsf(xyz[0] - pxyz[0]) > 1e-7) || ((double)fabsf(xyz[1] - pxyz[1]) > 1e-7) ||
+                     (((double)fabsf(xyz[2] - pxyz[2]) > 1e-7) && ((double)r2 > blind * blind));
+    if (!keep) continue;
+    float *o = out + 12 * m;
+    o[0] = xyz[0]; o[1] = xyz[1]; o[2] = xyz[2]; o[3] = 1.f; o[4] = o[5] = o[6] = o[7] = 0.f;
+    o[8] = (float)refl;                          /* intensity = reflectivity  :64 */
+    o[9] = (float)ot / (float)1000000;           /* curvature = offset_time / float(1000000), ms  :65-67 */
+    o[10] = o[11] = 0.f;
+    m++;
+  }
+  return m;
+}

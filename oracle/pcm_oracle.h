@@ -98,6 +98,9 @@ void orc_undistort(float *pts, long n, long stride_floats, long time_index, cons
 /* pcl::VoxelGrid down-sampling of a scan (laser_mapping.cc:323-328): out holds up to n records; returns the count, -1 on index overflow */
 long orc_voxel_downsample(const float *pts, long n, long stride_floats, float leaf, float *out);
 
+/* PointCloudPreprocess::AviaHandler (jueying_lio/src/pointcloud_preprocess.cc:44-88): n livox CustomPoint records of 20 bytes -> kept points, 12 floats each; returns their count */
+long orc_livox_filter(const unsigned char *msg, long n, int num_scans, int point_filter_num, double blind, float *out);
+
 /* pclomp GICP-BFGS functor (ndt_omp/include/pclomp/gicp_omp_impl.hpp:246-365, :519-529, :125-176); orc_gicp_bfgs.c */
 void orc_gicp_bfgs_apply_state(const float base[16], const double x[6], float T[16]);
 void orc_gicp_bfgs_r_derivative(const double x[6], const double R[9], double g[6]);

@@ -13,7 +13,7 @@ SYMBOLS = [
     "pcm_abi_version", "pcm_default_config", "pcm_create", "pcm_destroy", "pcm_last_error",
     "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
     "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
-    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_get_lio_members", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_set_covariances", "pcm_ndt_derivatives", "pcm_ndt_score", "pcm_fitness_score", "pcm_undistort", "pcm_voxel_downsample", "pcm_gicp_bfgs_set_correspondences", "pcm_gicp_bfgs_fdf", "pcm_gicp_bfgs_update_correspondences", "pcm_gicp_bfgs_get_correspondences", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
+    "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_get_lio_members", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_set_covariances", "pcm_ndt_derivatives", "pcm_ndt_score", "pcm_fitness_score", "pcm_undistort", "pcm_voxel_downsample", "pcm_livox_filter", "pcm_gicp_bfgs_set_correspondences", "pcm_gicp_bfgs_fdf", "pcm_gicp_bfgs_update_correspondences", "pcm_gicp_bfgs_get_correspondences", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
@@ -130,6 +130,7 @@ def load_library():
     L.pcm_map_incremental.argtypes = [vp, C.POINTER(PcmLioState), C.c_float, i32, C.POINTER(sz)]
     L.pcm_get_target.argtypes = [vp, vp, sz, C.POINTER(sz)]
     L.pcm_get_covariances.argtypes = [vp, C.c_int, vp, sz, C.POINTER(sz)]
+    L.pcm_livox_filter.argtypes = [vp, vp, sz, C.c_int, C.c_int, C.c_int, C.c_double, vp, sz, C.POINTER(sz)]
     L.pcm_set_covariances.argtypes = [vp, C.c_int, vp, sz, C.c_int]
     L.pcm_ndt_derivatives.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double), vp, vp]
     L.pcm_ndt_score.argtypes = [vp, vp, C.POINTER(C.c_double)]

@@ -573,10 +573,15 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
           const int DyDz = Dy * Dz;
           const int cell0 = ((cx - ox0) * Dy + (cy - oy0)) * Dz + (cz - oz0);
           uint16_t kh[27];
+          if (kp.num_neighbors == 27) {   // the common case without 27 scalar compare-and-branch pairs
   #pragma unroll
-          for (int g = 0; g < 27; g++) {
-            kh[g] = kNoCell;
-            if (g < kp.num_neighbors) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
+            for (int g = 0; g < 27; g++) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
+          } else {
+  #pragma unroll
+            for (int g = 0; g < 27; g++) {
+              kh[g] = kNoCell;
+              if (g < kp.num_neighbors) kh[g] = s_cell[cell0 + kNearby[g][0] * DyDz + kNearby[g][1] * Dz + kNearby[g][2]];
+            }
           }
           // a voxel's points are one run of s_pts that ends where the next voxel head (tag bit 31; the sentinel
           // s_pts[total] is one) begins.  The list carries byte offsets (k * 16) until the search is over.

@@ -1399,6 +1399,41 @@ int pcm_set_covariances(pcm_ctx* c, int target, const double* covs, size_t n, in
   return PCM_OK;
 }
 
+// PointCloudPreprocess::AviaHandler  (jueying_lio/src/pointcloud_preprocess.cc:44-88)
+int pcm_livox_filter(pcm_ctx* c, const void* custom_points, size_t n, int memory, int num_scans, int point_filter_num, double blind, void* out, size_t capacity_points, size_t* n_out) {
+  CHECK_CTX(c);
+  if ((!custom_points && n) || !out || !n_out) return PCM_ERR_INVALID_ARGUMENT;
+  if (capacity_points < n) { c->err = "the output buffer must hold as many records as the input"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (n > 0xffffffffull) { c->err = "too many points"; return PCM_ERR_INVALID_ARGUMENT; }
+  *n_out = 0;
+  if (n == 0) return PCM_OK;
+  HIPCK(c, hipSetDevice(c->device));
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t io = memory == PCM_MEM_HOST ? up(n * 20) + up(n * 48) : 0;
+  const size_t need = livox_filter_scratch_bytes(n) + io;
+  if (c->pre_arena_cap < need) {   // grow-only arena shared with the other pre-processing operators
+    if (c->pre_arena) hipFree(c->pre_arena);
+    c->pre_arena = nullptr; c->pre_arena_cap = 0;
+    HIPCK(c, hipMalloc(&c->pre_arena, need + need / 4));
+    c->pre_arena_cap = need + need / 4;
+  }
+  const void* src = custom_points;
+  void* dst = out;
+  char* scratch = c->pre_arena;
+  if (memory == PCM_MEM_HOST) {
+    char* d_in = c->pre_arena;
+    char* d_out = c->pre_arena + up(n * 20);
+    scratch = c->pre_arena + io;
+    HIPCK(c, hipMemcpyAsync(d_in, custom_points, n * 20, hipMemcpyHostToDevice, c->stream));
+    src = d_in; dst = d_out;
+  }
+  const int rc = livox_filter_device(c->stream, src, n, num_scans, point_filter_num, blind, dst, n_out, scratch, &c->err);
+  if (rc != PCM_OK) return rc;
+  if (memory == PCM_MEM_HOST && *n_out) HIPCK(c, hipMemcpyAsync(out, dst, *n_out * 48, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return PCM_OK;
+}
+
 // getSourceCovariances / getTargetCovariances  fast_gicp.hpp:64-70  (input order, row-major 3x3 blocks)
 int pcm_get_covariances(pcm_ctx* c, int target, double* out, size_t capacity_points, size_t* n) {
   CHECK_CTX(c);

@@ -79,6 +79,8 @@ int map_incremental_device(hipStream_t stream, const float4* scan, bool scan_reo
 // preprocess.hip
 int undistort_device(hipStream_t stream, void* d_points, size_t n, size_t stride, size_t time_off, const pcm_imu_pose* d_poses, int npose, const LioStateD& s, std::string* err);
 size_t voxel_downsample_scratch_bytes(size_t n);
+size_t livox_filter_scratch_bytes(size_t n);
+int livox_filter_device(hipStream_t stream, const void* d_msg, size_t n, int num_scans, int point_filter_num, double blind, void* d_out, size_t* n_out, void* scratch, std::string* err);
 int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size_t stride, float leaf, float* d_out, size_t* n_out, void* scratch, std::string* err);
 // gicp_bfgs.hip
 constexpr int kGicpBfgsMaxBlocks = 512;   // rows of the partial-sum table

@@ -261,4 +261,91 @@ int voxel_downsample_device(hipStream_t stream, const void* d_in, size_t n, size
 #undef CK
 }
 
+// ---------------------------------------------------------------------------
+// PointCloudPreprocess::AviaHandler  (jueying_lio/src/pointcloud_preprocess.cc:44-88): livox CustomMsg points -> PointXYZINormal cloud.
+// A raw point is 20 bytes {uint32 offset_time; float x, y, z; uint8 reflectivity, tag, line; pad}.  Point i >= 1 passes when its line and
+// tag do and i % point_filter_num == 0 (:58-61), and is kept when it differs from cloud_full_[i - 1]: the previous raw point if THAT one
+// passed, else the zero point resize() left (:50) -- the serial reading of the reference's par_unseq loop --, under the reference's own
+// operator precedence |dx| > 1e-7 || |dy| > 1e-7 || (|dz| > 1e-7 && r^2 > blind^2)  (:69-74).  Flag pass, exclusive scan, write pass:
+// the kept points leave in input order (:82-86), 48-byte records {x, y, z, 1, 0, 0, 0, 0, intensity, curvature, 0, 0}.
+// ---------------------------------------------------------------------------
+struct LivoxRaw { uint32_t offset_time; float x, y, z; uint8_t reflectivity, tag, line, pad; };
+static_assert(sizeof(LivoxRaw) == 20, "livox CustomPoint layout");
+
+__device__ inline bool livox_passes(const LivoxRaw& r, uint32_t i, int num_scans, uint32_t filter_num) {
+  return (int)r.line < num_scans && ((r.tag & 0x30) == 0x10 || (r.tag & 0x30) == 0x00) && (i % filter_num) == 0;
+}
+
+__global__ void __launch_bounds__(256) k_livox_flags(const LivoxRaw* __restrict__ msg, uint32_t n, int num_scans, uint32_t filter_num, double blind2, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint32_t keep = 0;
+  if (i >= 1) {
+    const LivoxRaw r = msg[i];
+    if (livox_passes(r, i, num_scans, filter_num)) {
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (i >= 2) {
+        const LivoxRaw rp = msg[i - 1];
+        if (livox_passes(rp, i - 1, num_scans, filter_num)) { px = rp.x; py = rp.y; pz = rp.z; }
+      }
+      const float r2 = r.x * r.x + r.y * r.y + r.z * r.z;
+      keep = ((double)fabsf(r.x - px) > 1e-7 || (double)fabsf(r.y - py) > 1e-7 || ((double)fabsf(r.z - pz) > 1e-7 && (double)r2 > blind2)) ? 1u : 0u;
+    }
+  }
+  flag[i] = keep;
+}
+
+__global__ void __launch_bounds__(256) k_livox_write(const LivoxRaw* __restrict__ msg, uint32_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const LivoxRaw r = msg[i];
+  float4* o = out + 3 * (size_t)pos[i];
+  o[0] = make_float4(r.x, r.y, r.z, 1.f);
+  o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+  o[2] = make_float4((float)r.reflectivity, __fdiv_rn((float)r.offset_time, (float)1000000), 0.f, 0.f);   // intensity; curvature = offset_time / float(1000000), ms
+}
+
+size_t livox_filter_scratch_bytes(size_t n) {
+  size_t t = 0;
+  uint32_t* v = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, t, v, v, 0u, n, rocprim::plus<uint32_t>(), nullptr);
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  return 2 * up(4 * n) + up(t);
+}
+
+int livox_filter_device(hipStream_t stream, const void* d_msg, size_t n, int num_scans, int point_filter_num, double blind, void* d_out, size_t* n_out, void* scratch, std::string* err) {
+  *n_out = 0;
+  if (n < 2) return PCM_OK;
+  if (point_filter_num < 1 || num_scans < 0) { *err = "point_filter_num must be >= 1"; return PCM_ERR_INVALID_ARGUMENT; }
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  char* cur = static_cast<char*>(scratch);
+  uint32_t* flag = reinterpret_cast<uint32_t*>(cur); cur += up(4 * n);
+  uint32_t* pos = reinterpret_cast<uint32_t*>(cur); cur += up(4 * n);
+  void* tmp = cur;
+  size_t tmp_bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, tmp_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), stream);
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  const LivoxRaw* msg = static_cast<const LivoxRaw*>(d_msg);
+#define CK(x)                                                                    \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); return PCM_ERR_HIP; } \
+  } while (0)
+  k_livox_flags<<<nb, 256, 0, stream>>>(msg, (uint32_t)n, num_scans, (uint32_t)point_filter_num, blind * blind, flag);
+  CK(hipGetLastError());
+  CK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, pos, 0u, n, rocprim::plus<uint32_t>(), stream));
+  uint32_t tails[2] = {0, 0};
+  CK(hipMemcpyAsync(&tails[0], flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&tails[1], pos + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  CK(hipStreamSynchronize(stream));
+  const size_t m = (size_t)tails[0] + tails[1];
+  if (m) {
+    k_livox_write<<<nb, 256, 0, stream>>>(msg, (uint32_t)n, flag, pos, static_cast<float4*>(d_out));
+    CK(hipGetLastError());
+  }
+  *n_out = m;
+  return PCM_OK;
+#undef CK
+}
+
 }  // namespace pcm

@@ -276,6 +276,16 @@ class Registration:
         self._check(self._L.pcm_gicp_bfgs_get_correspondences(self._h, isrc.ctypes.data, itgt.ctypes.data, M.ctypes.data, m))
         return isrc, itgt, M.reshape(-1, 3, 3)
 
+    def livox_filter(self, msg_points, num_scans: int = 6, point_filter_num: int = 1, blind: float = 0.01) -> np.ndarray:
+        """PointCloudPreprocess::AviaHandler (pointcloud_preprocess.cc:44-88): livox CustomPoint records (20-byte structured array:
+        offset_time u4, x y z f4, reflectivity tag line u1, pad) -> (m, 12) float32 pcl::PointXYZINormal records in input order."""
+        a = np.ascontiguousarray(msg_points)
+        assert a.dtype.itemsize == 20
+        out = np.zeros((max(len(a), 1), 12), np.float32)
+        m = C.c_size_t()
+        self._check(self._L.pcm_livox_filter(self._h, a.ctypes.data, len(a), capi.MEM_HOST, int(num_scans), int(point_filter_num), float(blind), out.ctypes.data, len(out), C.byref(m)))
+        return out[:m.value].copy()
+
     def get_target(self) -> np.ndarray:
         """(M,3) current target points in insertion order."""
         n = C.c_size_t()

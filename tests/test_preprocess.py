@@ -114,3 +114,75 @@ def test_voxel_downsample_matches_oracle(pcm):
     with pytest.raises(pcm.PcmError):
         far = _scan_for_downsample(6); far[0, :3] = 1e7
         reg.voxel_downsample(far, 0.001)                           # index overflow, as PCL refuses it
+
+
+# ---- PointCloudPreprocess::AviaHandler (pointcloud_preprocess.cc:44-88) ------------------------------------------------------
+def _livox_msg(n=20000, seed=3):
+    """A livox CustomMsg-like frame: mostly good returns, with noise tags, lines beyond num_scans, exact repeats of the previous
+    point (the duplicate test), points inside the blind radius that differ only in z, and an all-zero return."""
+    from oracle.loader import LIVOX_POINT
+    rng = np.random.default_rng(seed)
+    a = np.zeros(n, LIVOX_POINT)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p = (d * rng.uniform(0.5, 80.0, (n, 1))).astype(np.float32)
+    a["x"], a["y"], a["z"] = p[:, 0], p[:, 1], p[:, 2]
+    a["offset_time"] = np.sort(rng.integers(0, 100_000_000, n)).astype(np.uint32)       # ns within a 100 ms frame
+    a["reflectivity"] = rng.integers(0, 256, n)
+    a["tag"] = rng.choice([0x00, 0x10, 0x20, 0x30, 0x11, 0x05, 0x25], n, p=[0.3, 0.4, 0.05, 0.05, 0.1, 0.05, 0.05])
+    a["line"] = rng.integers(0, 8, n)                                                  # num_scans = 6: lines 6, 7 are dropped
+    if n > 200:
+        rep = rng.choice(np.arange(2, n), n // 20, replace=False)                      # exact repeats of the previous raw point
+        for k in ("x", "y", "z"):
+            a[k][rep] = a[k][rep - 1]
+        near = rng.choice(np.arange(2, n), n // 20, replace=False)                     # same x, y as the previous point, tiny range
+        a["x"][near] = a["x"][near - 1]; a["y"][near] = a["y"][near - 1]; a["z"][near] = a["z"][near - 1] + np.float32(0.001)
+        a["x"][100] = a["y"][100] = a["z"][100] = 0.0
+    return a
+
+
+def _avia_reference(a, num_scans, filt, blind):
+    """The handler written out in numpy float32/float64, serial reading of the par_unseq loop."""
+    n = len(a)
+    i = np.arange(n)
+    passes = (a["line"] < num_scans) & (((a["tag"] & 0x30) == 0x10) | ((a["tag"] & 0x30) == 0x00)) & (i % filt == 0) & (i >= 1)
+    prev = np.zeros((n, 3), np.float32)
+    cp = np.r_[False, passes[:-1]]
+    xyz = np.stack([a["x"], a["y"], a["z"]], 1)
+    prev[cp] = np.r_[np.zeros((1, 3), np.float32), xyz[:-1]][cp]
+    d = np.abs(xyz - prev).astype(np.float64)
+    r2 = (xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1] + xyz[:, 2] * xyz[:, 2]).astype(np.float64)
+    keep = passes & ((d[:, 0] > 1e-7) | (d[:, 1] > 1e-7) | ((d[:, 2] > 1e-7) & (r2 > blind * blind)))
+    out = np.zeros((int(keep.sum()), 12), np.float32)
+    out[:, :3] = xyz[keep]; out[:, 3] = 1.0
+    out[:, 8] = a["reflectivity"][keep].astype(np.float32)
+    out[:, 9] = a["offset_time"][keep].astype(np.float32) / np.float32(1000000)
+    return out
+
+
+@pytest.mark.parametrize("filt,blind", [(1, 0.01), (2, 0.1), (3, 4.0)])      # header default; config/livox.yaml; config/horizon.yaml
+def test_livox_filter_oracle_against_a_numpy_statement(filt, blind):
+    from oracle.loader import livox_filter
+    a = _livox_msg()
+    got = livox_filter(a, 6, filt, blind)
+    want = _avia_reference(a, 6, filt, blind)
+    assert 0.2 * len(a) / filt < len(got) < len(a) and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if filt == 1:   # the reference's precedence: a point inside the blind radius survives unless it differs from its predecessor in z only
+        assert (np.linalg.norm(livox_filter(a, 6, 1, 4.0)[:, :3], axis=1) < 4.0).sum() > 100
+
+
+def test_livox_filter_tiny_inputs():
+    from oracle.loader import livox_filter, LIVOX_POINT
+    assert len(livox_filter(np.zeros(0, LIVOX_POINT))) == 0 and len(livox_filter(_livox_msg(1))) == 0     # index 0 is never taken (:53-56)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt,blind", [(1, 0.01), (2, 0.1), (3, 4.0)])
+def test_gpu_livox_filter_equals_the_oracle(pcm, filt, blind):
+    from oracle.loader import livox_filter
+    g = pcm.P2PlaneRegistration(0)
+    for n in (20000, 257, 2, 1):
+        a = _livox_msg(n)
+        want = livox_filter(a, 6, filt, blind)
+        got = g.livox_filter(a, 6, filt, blind)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
