@@ -240,6 +240,25 @@ public:
     this->cfg_.num_neighbors = 1;
   }
   void setCorrespondenceRandomness(int) {}                                                       // a no-op there too (fast_vgicp_cuda_impl.hpp:37-38)
+  // setNearestNeighborSearchMethod (fast_vgicp_cuda_impl.hpp:64-66): CPU_PARALLEL_KDTREE and GPU_BRUTEFORCE both give the exact
+  // k nearest neighbours the covariances are built from -- one device implementation serves both; the RBF-kernel covariances
+  // (covariance_estimation_rbf.cu) are a different estimator and are not built: selecting them is an error at align() time
+  enum class NearestNeighborMethod { CPU_PARALLEL_KDTREE, GPU_BRUTEFORCE, GPU_RBF_KERNEL };      // fast_vgicp_cuda.hpp:21
+  void setNearestNeighborSearchMethod(NearestNeighborMethod m) { rbf_selected_ = m == NearestNeighborMethod::GPU_RBF_KERNEL; }
+  void setKernelWidth(double kernel_width, double max_dist = -1.0) {                             // fast_vgicp_cuda_impl.hpp:46-52 (RBF mode only)
+    kernel_width_ = kernel_width;
+    kernel_max_dist_ = max_dist <= 0.0 ? kernel_width * 5.0 : max_dist;
+  }
+
+protected:
+  void computeTransformation(typename GicpRegistration<PointSource, PointTarget>::PointCloudSource& output, const typename GicpRegistration<PointSource, PointTarget>::Matrix4& guess) override {
+    if (rbf_selected_) throw std::runtime_error("pcm_amd::VgicpCudaRegistration: NearestNeighborMethod::GPU_RBF_KERNEL (RBF-kernel covariances) is not built");
+    GicpRegistration<PointSource, PointTarget>::computeTransformation(output, guess);
+  }
+  bool rbf_selected_ = false;
+  double kernel_width_ = 0.25, kernel_max_dist_ = 3.0;                                           // cuda/fast_vgicp_cuda.cu:25-26
+
+public:
   void setNeighborSearchMethod(NeighborSearchMethod m, double radius = -1.0) { detail::set_search_method(this->cfg_, m, radius); }
 };
 
@@ -271,7 +290,10 @@ public:
     this->transformation_epsilon_ = 0.1;
   }
   void setStepSize(double s) { this->cfg_.ndt_step_size = static_cast<float>(s); }               // ndt_omp.h:166
-  void setOulierRatio(double r) { this->cfg_.ndt_outlier_ratio = static_cast<float>(r); }        // ndt_omp.h:184 (sic)
+  double getStepSize() const { return this->cfg_.ndt_step_size; }                                 // ndt_omp.h:157
+  void setOutlierRatio(double r) { this->cfg_.ndt_outlier_ratio = static_cast<float>(r); }       // ndt_omp.h:188
+  double getOutlierRatio() const { return this->cfg_.ndt_outlier_ratio; }                         // ndt_omp.h:179
+  float getResolution() const { return this->cfg_.voxel_resolution; }                             // ndt_omp.h:141
   void setNeighborhoodSearchMethod(NeighborSearchMethodOmp m) {                                  // ndt_omp.h:198
     this->cfg_.num_neighbors = m == KDTREE ? 0 : (m == DIRECT26 ? 27 : (m == DIRECT7 ? 7 : 1));
   }

@@ -42,14 +42,14 @@ int main() {
   { pcm_amd::GicpRegistration<P, P> r; r.setCorrespondenceRandomness(20); r.setRegularizationMethod(pcm_amd::RegularizationMethod::PLANE); s += common_surface(r, src, tgt); s += r.getSourceCovariances().size() + r.getTargetCovariances().size(); r.setSourceCovariances(r.getSourceCovariances()); r.setTargetCovariances(r.getTargetCovariances()); }
   { pcm_amd::VgicpRegistration<P, P> r; r.setResolution(1.0); r.setNeighborSearchMethod(pcm_amd::NeighborSearchMethod::DIRECT7); r.setVoxelAccumulationMode(pcm_amd::VoxelAccumulationMode::ADDITIVE); s += common_surface(r, src, tgt); }
   { pcm_amd::NdtRegistration<P, P> r; r.setDistanceMode(pcm_amd::NDTDistanceMode::D2D); r.setNeighborSearchMethod(pcm_amd::NeighborSearchMethod::DIRECT7, -1.0); s += common_surface(r, src, tgt); }
-  { pcm_amd::VgicpCudaRegistration<P, P> r; r.setResolution(1.0); r.setCorrespondenceRandomness(20); r.setNeighborSearchMethod(pcm_amd::NeighborSearchMethod::DIRECT_RADIUS, 1.5); s += common_surface(r, src, tgt); }
+  { pcm_amd::VgicpCudaRegistration<P, P> r; r.setResolution(1.0); r.setCorrespondenceRandomness(20); r.setNeighborSearchMethod(pcm_amd::NeighborSearchMethod::DIRECT_RADIUS, 1.5); r.setNearestNeighborSearchMethod(pcm_amd::VgicpCudaRegistration<P, P>::NearestNeighborMethod::GPU_BRUTEFORCE); r.setKernelWidth(0.5, 3.0); s += common_surface(r, src, tgt); }
   { // jueying_slam/src/localization.cpp:162-189, through the pclomp spellings
     std::shared_ptr<pclomp::NormalDistributionsTransform<P, P>> ndt(new pclomp::NormalDistributionsTransform<P, P>());
     ndt->setTransformationEpsilon(0.01);
     ndt->setResolution(1.0);
     ndt->setNeighborhoodSearchMethod(pclomp::DIRECT7);
     ndt->setStepSize(0.1);
-    ndt->setOulierRatio(0.55);
+    ndt->setOutlierRatio(0.55); (void)ndt->getOutlierRatio(); (void)ndt->getStepSize(); (void)ndt->getResolution();
     s += common_surface(*ndt, src, tgt);
     s += ndt->getTransformationProbability() + ndt->getMaxEigen() + ndt->calculateScore();
   }
