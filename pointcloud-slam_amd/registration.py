@@ -112,7 +112,17 @@ class Registration:
     def set_optimizer(self, name): self._set(optimizer=name)                       # lsq_optimizer_type_
     def set_resolution(self, r): self._set(voxel_resolution=float(r))              # fast_vgicp_impl.hpp:28-30
     def set_num_neighbors(self, n): self._set(num_neighbors=int(n))                # setNeighborSearchMethod / ivox_nearby_type
-    def set_max_correspondence_distance(self, d): self._set(max_range=float(d), max_corr_dist=float(d))
+
+    def set_neighbor_search_method(self, method: str, radius: float = -1.0):
+        """pygicp's set_neighbor_search_method (src/python/main.cpp:195-212): DIRECT1 / DIRECT7 / DIRECT27, or DIRECT_RADIUS with the radius in
+        voxels for the CUDA-core models."""
+        if method == "DIRECT_RADIUS":
+            self._set(neighbor_search_radius=float(radius))
+        else:
+            self._set(neighbor_search_radius=0.0, num_neighbors={"DIRECT1": 1, "DIRECT7": 7, "DIRECT27": 27}[method])
+
+    def set_max_correspondence_distance(self, d): self._set(max_corr_dist=float(d))   # corr_dist_threshold_ (GICP family); the point-to-plane search radius is set_max_range
+    def set_max_range(self, r): self._set(max_range=float(r))                        # IVox max_range (ivox3d.h:80)
     def set_num_threads(self, n): pass                                              # setNumThreads: no meaning on the GPU
     def set_stream(self, hip_stream: int): self._check(self._L.pcm_set_stream(self._h, hip_stream))
     def set_profiling(self, flags: int): self._check(self._L.pcm_set_profiling(self._h, int(flags)))
@@ -359,7 +369,7 @@ class PclNdtRegistration(Registration):
     defaults = {"voxel_resolution": 1.0, "num_neighbors": 7, "max_iterations": 35, "translation_eps": 0.1}
 
     def set_step_size(self, s): self._set(ndt_step_size=float(s))                  # setStepSize       ndt_omp.h
-    def set_outlier_ratio(self, r): self._set(ndt_outlier_ratio=float(r))          # setOulierRatio    ndt_omp.h
+    def set_outlier_ratio(self, r): self._set(ndt_outlier_ratio=float(r))          # setOutlierRatio   ndt_omp.h:188
 
 
 class VgicpCudaRegistration(Registration):
