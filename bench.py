@@ -359,7 +359,7 @@ def main():
                          "traffic": traffic, "kernel": "k_linearize", "avg_launch_ms": avg_launch_ms,
                          "algorithmic_bytes_per_point_pass": b_pi, "candidates_per_point": kbar, "slots_probed_per_point": probes,
                          "point_passes_per_launch": st["point_passes"] * share / timed, "launches": launches, "launches_timed": st["timed_launches"],
-                         "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]),
+                         "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]), "tiles_staged_through_lds": sc["tiles_lds_points"] / max(1, sc["tiles"]),
                          "residual_kernel_avg_ms": (st["residual_ms"] / launches) if st["residual_ms"] > 0 else None},
         }
         # the CPU leg is timed on rank 0 of the single-GPU run only (the other ranks would idle behind it)

@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 pl = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
-  bool use_lds = false;
+  bool use_lds = false, box_ok = false;
   bool ref_fit = false, ref_ok = false;   // LIO reference semantics: esti_plane ran for this point (pl = what it wrote) / what it returned
   if (do_search) {
     // ---- voxel bounding box of the tile ---------------------------------------------------------
@@ -486,6 +486,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
     }
     __syncthreads();
     use_lds = s_box[7] != 0;   // uniform over the workgroup
+    if (STATS) box_ok = use_lds;   // counters pass: the tile's voxel box and bricks fitted (the staged points may still not)
     PCM_STAMP(0)   // load + transform + tile box
 
     Best best;
@@ -891,7 +892,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
     if (lane == 0) {
       atomicAdd(&stats[0], c);
       atomicAdd(&stats[1], pr);
-      if (wave == 0) { atomicAdd(&stats[2], use_lds ? 1ull : 0ull); atomicAdd(&stats[3], 1ull); }
+      if (wave == 0) { atomicAdd(&stats[2], use_lds ? 1ull : 0ull); atomicAdd(&stats[3], 1ull); atomicAdd(&stats[4], box_ok ? 1ull : 0ull); }
     }
   }
 }

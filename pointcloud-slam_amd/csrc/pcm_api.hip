@@ -661,7 +661,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     c0->stats.candidates += hs[0];
     c0->stats.slots_probed += hs[1];
     c0->stats.tiles += hs[3];
-    c0->stats.tiles_lds_grid += hs[2];
+    c0->stats.tiles_lds_grid += hs[4];
     c0->stats.tiles_lds_points += hs[2];
   }
   if (stats_on) {
