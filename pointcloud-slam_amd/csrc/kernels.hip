@@ -321,30 +321,43 @@ __global__ void __launch_bounds__(256) k_finish_round(const PairDesc* __restrict
     }
     if (threadIdx.x < kNumSums) s_tot[threadIdx.x] = t;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      if (kp.do_step) {
-        PairState& st = states[pair];
+    if (kp.do_step) {
+      // The solver step works on a copy of the pair's state in LDS: its ~200 loads and stores (several of them behind calls, i.e.
+      // through memory and dependent on each other) then cost an LDS access each instead of a trip to L2 -- the copy in and the
+      // copy out are one cooperative trip each.  Only this workgroup writes an ACTIVE pair's state (the hand-off below touches
+      // pairs that are waiting), so the copy cannot go stale.
+      __shared__ PairState s_state;
+      static_assert(sizeof(PairState) % sizeof(double) == 0, "PairState is copied in doubles");
+      constexpr int kStateDoubles = (int)(sizeof(PairState) / sizeof(double));
+      double* ls = reinterpret_cast<double*>(&s_state);
+      double* gs = reinterpret_cast<double*>(&states[pair]);
+      for (int k = threadIdx.x; k < kStateDoubles; k += 256) ls[k] = gload_d(gs + k);
+      __syncthreads();
+      if (threadIdx.x == 0) {
         if (mode == MODE_LINEARIZE) {
           double H[36], b[6], cost;
           int inl;
           unpack_sums(s_tot, H, b, &cost, &inl);
-          after_linearize(st, lp, H, b, cost, inl);
+          after_linearize(s_state, lp, H, b, cost, inl);
         } else {
-          after_trial(st, lp, s_tot[27]);
+          after_trial(s_state, lp, s_tot[27]);
         }
         // batch window: a pair that just finished hands its slot to the next queued pair.  The queued pair's own workgroup of THIS
         // launch may already have read its mode (WAIT), so it is only marked PENDING here and promoted by its own workgroup in a
         // later step launch -- activating it in place raced with that read (stale partial rows summed; round-1 advisor finding)
-        if (st.mode == MODE_DONE && queue) {
+        if (s_state.mode == MODE_DONE && queue) {
           const unsigned int next = atomicAdd(queue, 1u);
           if (next < (unsigned int)npairs) states[next].mode = MODE_PENDING;
         }
-      } else {
-        for (int k = 0; k < kNumSums; k++) sums_out[pair * kPartialStride + k] = s_tot[k];
+        if (write_flags) __hip_atomic_store(flags_row + pair, (unsigned char)(s_state.mode != MODE_DONE ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      __syncthreads();
+      for (int k = threadIdx.x; k < kStateDoubles; k += 256) gstore_d(gs + k, ls[k]);
+      return;
     }
+    if (threadIdx.x == 0) for (int k = 0; k < kNumSums; k++) sums_out[pair * kPartialStride + k] = s_tot[k];
   }
-  // status of EVERY pair after the last step launch of the round: 1 = still active, 2 = done
+  // status of every pair this launch did not step, after the last step launch of the round: 1 = still active, 2 = done
   if (write_flags && threadIdx.x == 0)
     __hip_atomic_store(flags_row + pair, (unsigned char)(states[pair].mode != MODE_DONE ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
