@@ -12,7 +12,7 @@
 #include <stdint.h>
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define PCM_HD __host__ __device__ inline
+#define PCM_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define PCM_HD inline   // plain host build: tests/test_capi_and_host.py replays GN / LM traces through this header with g++
 #endif
