@@ -71,7 +71,8 @@ class PcmStats(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libpcm_amd.so")
+    """The in-tree build; PCM_AMD_LIBRARY names another build of the same ABI (A/B measurements of two builds on one box)."""
+    return os.environ.get("PCM_AMD_LIBRARY") or os.path.join(_HERE, "libpcm_amd.so")
 
 
 def build_library(force: bool = False) -> str:
