@@ -223,3 +223,40 @@ def test_shard_helpers():
     assert sh.split_sub_batches(3, 8) == [[0], [1], [2]]
     recs = sh.pack_results([{"T64": np.eye(4), "iterations": 3, "converged": 1}])
     assert recs.size == sh.RECORD_BYTES and sh.records_to_results(recs)[0]["iterations"] == 3
+
+
+def test_slot_schedulers_without_a_process_group():
+    """run_rotating_steps / run_pipelined_steps on one rank (no collective): every pass runs once, on the slot the schedule names, the
+    result of the last pass comes back, and an exception in a slot surfaces in the caller instead of hanging the other threads."""
+    sys.path.insert(0, ROOT)
+    import threading
+    import pointcloud_slam_amd as pcm
+    sh = pcm.sharding
+    lock = threading.Lock()
+    seen = []
+
+    def step(slot, wait_prev):
+        assert wait_prev is None                      # no gather: nothing to wait for
+        with lock:
+            seen.append(slot)
+            return len(seen)
+
+    last = sh.run_rotating_steps(7, 3, step)
+    assert sorted(seen) == sorted([s % 3 for s in range(7)]) and last is not None
+    seen.clear()
+    assert sh.run_rotating_steps(2, 5, step) is not None and sorted(seen) == [0, 1]      # more slots than passes
+    seen.clear()
+    assert len(sh.run_pipelined_steps(4, 2, step)) == 2 and sorted(seen) == [0] * 4 + [1] * 4
+
+    def bad(slot, wait_prev):
+        if slot == 1:
+            raise ValueError("boom")
+        return 1
+
+    with pytest.raises(ValueError):
+        sh.run_rotating_steps(6, 2, bad)
+    with pytest.raises(ValueError):
+        sh.run_pipelined_steps(3, 2, bad)
+    gathered = []
+    with pytest.raises(ValueError):                   # with a gather thread: it must be released, not left waiting for the dead slot
+        sh.run_rotating_steps(6, 2, bad, gather=lambda j: gathered.append(j))
