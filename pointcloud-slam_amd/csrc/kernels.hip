@@ -388,17 +388,27 @@ constexpr uint16_t kNoCell = 0xffffu;
 template <bool STATS, bool TIMING, bool WRITE_PLANES, bool LIO, bool FUSED = false>
 __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
                                                       unsigned long long* __restrict__ stats, LsqParams lp = LsqParams{}, unsigned char* __restrict__ flags_row = nullptr) {
-  const int pair = PCM_PAIR_OF(kp, blockIdx.y);
+  // XCD-aware placement, balanced: workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Inside every run of 64
+  // consecutive tiles of a pair the ids are transposed (8 x 8), so that 8 neighbouring tiles -- neighbours on the scan's Morton curve,
+  // readers of the same map bricks -- share an XCD while every XCD still takes an equal share of every pair.
+  // (Handing every XCD one contiguous run of the whole grid instead lost 3.5 %: profiles/r02_xcd_aware_mapping_experiment.txt.)
+  uint32_t tile_x = blockIdx.x;
+  {
+    const uint32_t base = blockIdx.x & ~63u, w = blockIdx.x & 63u;
+    if (base + 64u <= gridDim.x) tile_x = base + (w & 7u) * 8u + (w >> 3);   // the last, partial run keeps its order
+  }
+  const uint32_t slot_y = blockIdx.y;
+  const int pair = PCM_PAIR_OF(kp, slot_y);
   if (states[pair].mode != MODE_LINEARIZE) {
     if constexpr (FUSED) {   // a pair that finished since the host last looked: its status byte of this round still has to land
-      if (blockIdx.x == 0 && threadIdx.x == 0)
+      if (tile_x == 0 && threadIdx.x == 0)
         __hip_atomic_store(flags_row + pair, (unsigned char)(states[pair].mode != MODE_DONE ? 1 : 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
   }
   const PairDesc d = descs[pair];
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (blockIdx.x * 256u >= d.src.num_points) return;
+  const uint32_t i = tile_x * 256u + threadIdx.x;
+  if (tile_x * 256u >= d.src.num_points) return;
   const bool live = i < d.src.num_points;
   const PoseF P = load_pose(states[pair].x0);
   const TargetView tg = d.tgt;
@@ -804,7 +814,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
       double v = 0.0;
 #pragma unroll
       for (int g = 0; g < 8; g++) v += s_grp[g * kLioStride + threadIdx.x];
-      gstore_d(d.partials + (size_t)blockIdx.x * kLioStride + threadIdx.x, v);
+      gstore_d(d.partials + (size_t)tile_x * kLioStride + threadIdx.x, v);
     }
   } else {
     // ---- residual / Jacobian of this lane's point -> one 8-float row in LDS ---------------------------
@@ -855,7 +865,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
         double v = 0.0;
   #pragma unroll
         for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
-        gstore_d(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+        gstore_d(d.partials + (size_t)tile_x * kPartialStride + threadIdx.x, v);
       }
     } else {
       // In-launch hand-off of the partial rows to the workgroup that completes the pair's round (no second launch, no
@@ -872,7 +882,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
           double v = 0.0;
   #pragma unroll
           for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
-          gstore_d_wt(d.partials + (size_t)blockIdx.x * kPartialStride + threadIdx.x, v);
+          gstore_d_wt(d.partials + (size_t)tile_x * kPartialStride + threadIdx.x, v);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
