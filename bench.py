@@ -33,6 +33,36 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 SLOT_BYTES = 16                # hash slot  
 POINT_BYTES = 16               # float4 query / map point
+# VALU issue ceiling of the chip: 256 CUs x 4 SIMDs, one wave64 vector instruction per SIMD every 2 cycles at 2.4 GHz
+# (/opt/skills/guides/MI355X_MICROARCH.md, "Wave scheduling" and the cycle-constants table; measured here 2.4-2.7 cycles:
+# profiles/r02_valu_issue_rate.txt), in G wave-instructions per second
+VALU_PEAK_GIPS = 1024 * 2.4 / 2.0
+
+
+def source_key():
+    """Hash of the kernel sources: ties a committed counter profile to the binary it was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pointcloud-slam_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(name, workload_key):
+    """A committed counter summary under profiles/ (rocprofv3 --pmc passes cannot run inside the timed process); returns the dict
+    and whether it was taken on this workload with these kernel sources."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, False
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception:
+        return None, False
+    return d, bool(d.get("workload_key") == workload_key and d.get("source_key") == source_key())
 
 
 def _gen_pair(args):
@@ -59,11 +89,12 @@ def generate_pairs(ids, n_scan, n_map, workers):
         return pool.map(_gen_pair, jobs)
 
 
-def cpu_baseline(pairs, cfg, budget_s):
+def cpu_baseline(pairs, cfg, budget_s, threads=None):
     """Oracle (CPU restatement of the reference path) timed on this host's cores on
     a bounded sample of the same workload.  A reported baseline, not the target."""
     from oracle import Oracle
-    threads = min(len(os.sched_getaffinity(0)), 16)   # the GPU box's CPU share for one GPU
+    if threads is None:
+        threads = min(len(os.sched_getaffinity(0)), 16)   # the GPU box's CPU share for one GPU
     t_all = time.perf_counter()
     n_done, t_align, iters, results = 0, 0.0, [], []
     for scan, submap, guess, _ in pairs:
@@ -297,6 +328,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, t_cold = float(t[0]), float(t[1])
 
+    # single-stream pass (untimed): the dominant kernel alone on the device, HIP events around EVERY launch on the launch stream
+    # -- the two-slot figure above includes the time a launch shares the CUs with the other slot's grid
+    lead[0].reset_stats()
+    lead[0].set_profiling(1)
+    n_single = max(2, min(10, args.steps))
+    if rotate:
+        sharding.run_rotating_steps(n_single, 1, sub_step, None, 0.0, on_thread_start=lambda: torch.cuda.set_device(dev_index))
+    else:
+        sharding.run_pipelined_steps(n_single, 1, sub_step, None, 0.0, on_thread_start=lambda: torch.cuda.set_device(dev_index))
+    torch.cuda.synchronize()
+    s1 = lead[0].stats()
+    lead[0].set_profiling(0)
+
     # counters pass (untimed): candidates / probes per point for the algorithmic-byte model
     for j in range(S):
         lead[j].reset_stats()
@@ -320,26 +364,48 @@ def main():
     value = total_regs / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # roofline of the dominant kernel (k_linearize): algorithmic bytes per point-iteration
-    # = query float4 + 27 hash slots + K-bar candidate float4s  (SURVEY.md §8d, P2PLANE exact 5-NN row)
-    b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
+    # ---- roofline of the dominant kernel (k_linearize_flat) ------------------------------------------------------------
+    # The kernel is a gather + reduction served from LDS: its physical HBM traffic is a few percent of the peak, and the
+    # SURVEY §8(d) byte model ("no reuse assumed": query + 27 slots + K-bar candidates per point pass) prices bytes the LDS staging
+    # never moves -- round 2's fraction against it exceeded 1.  What bounds it is vector-instruction issue: the roofline is
+    # wave-instructions per second against 1024 SIMDs x 2.4 GHz / 2 cycles.  Instructions per wave come from a committed
+    # SQ_INSTS_VALU / SQ_WAVES pass of the same sources (profiles/pmc_valu.json, tools/r03_counters.sh); time is the step's wall time.
+    workload_key = "%d_%d_%d_%s" % (args.scan_points, args.map_points, n_local, args.optimizer)
     launches = max(1, st["linearize_launches"])
     timed = max(1, st["timed_launches"])
-    # the timed launches' share of the point passes: by the length of their pair lists
-    share = st["timed_pair_slots"] / max(1, st["launched_pair_slots"])
-    bytes_per_launch = st["point_passes"] * share * b_pi / timed
-    avg_launch_ms = st["linearize_ms"] / timed
-    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("workload_key") == "%d_%d_%d_%s" % (args.scan_points, args.map_points, n_local, args.optimizer):
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    share = st["timed_pair_slots"] / max(1, st["launched_pair_slots"])   # the timed launches' share of the point passes: by the length of their pair lists
+    pp_per_step = st["point_passes"] / args.steps                         # point passes of this rank per step
+    waves_per_step = pp_per_step / 64.0
+    avg_launch_ms = st["linearize_ms"] / timed                            # two slots: sampled launches, other slot's grid sharing the device
+    pp_per_timed_launch = st["point_passes"] * share / timed
+    single_launch_ms = s1["linearize_ms"] / max(1, s1["timed_launches"])  # the kernel alone on the device
+    pp_per_single_launch = s1["point_passes"] / max(1, s1["timed_launches"])
+    valu, valu_ok = load_profile("pmc_valu.json", workload_key)
+    traffic_p, traffic_ok = load_profile("pmc_traffic.json", workload_key)
+    valu_per_wave = float(valu["valu_per_wave"]) if valu else None
+    b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
+    roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GIPS, "kernel": "k_linearize_flat",
+            "achieved": None, "frac": None, "traffic": None}
+    if valu_per_wave:
+        ach = valu_per_wave * waves_per_step / (ms_per_step * 1e-3) / 1e9
+        alone = valu_per_wave * (pp_per_single_launch / 64.0) / (single_launch_ms * 1e-3) / 1e9 if single_launch_ms > 0 else None
+        roof.update({"achieved": ach, "frac": ach / VALU_PEAK_GIPS,
+                     "valu_instructions_per_wave": valu_per_wave, "counters_match_binary": valu_ok, "counters_file": "profiles/pmc_valu.json",
+                     "wave_cycles_waiting_frac": valu.get("wait_any_frac"), "wave_cycles_issue_stalled_frac": valu.get("wait_inst_any_frac"),
+                     "kernel_alone_achieved": alone, "kernel_alone_frac": (alone / VALU_PEAK_GIPS) if alone else None})
+    if traffic_p:
+        hb = float(traffic_p["hbm_bytes_per_launch"])   # FETCH_SIZE x 2 + WRITE_SIZE of one launch of the profiled run (its launches carry the same mean pair count)
+        roof.update({"traffic": hb, "traffic_match_binary": traffic_ok,
+                     "hbm_GBps_physical": hb / (single_launch_ms * 1e-3) / 1e9 if single_launch_ms > 0 else None,
+                     "hbm_frac_physical": hb / (single_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if single_launch_ms > 0 else None})
+    roof.update({"avg_launch_ms_two_slots": avg_launch_ms, "point_passes_per_launch_two_slots": pp_per_timed_launch,
+                 "avg_launch_ms_single_stream": single_launch_ms, "point_passes_per_launch_single_stream": pp_per_single_launch,
+                 "launches_per_step": launches / args.steps,
+                 # reconciliation: sum of the dominant kernel's launch times per step over the step's wall time; > 1 = the two slots' grids overlap
+                 "sum_launch_ms_over_step_ms": (launches / args.steps) * avg_launch_ms / ms_per_step,
+                 "algorithmic_bytes_per_point_pass": b_pi, "algorithmic_GBps_informational": pp_per_step * b_pi / (ms_per_step * 1e-3) / 1e9,
+                 "candidates_per_point": kbar, "slots_probed_per_point": probes,
+                 "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]), "tiles_staged_through_lds": sc["tiles_lds_points"] / max(1, sc["tiles"])})
 
     out = None
     if rank == 0:
@@ -349,24 +415,23 @@ def main():
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 geometry / f64 accumulate", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence)"
-                                   % (args.scan_points, args.map_points, args.optimizer),
+            "config": {"workload": "configs[1]: %d-pt Livox-shaped scan vs %d-pt submap, point-to-plane ICP (5-NN voxel hash, %s to convergence), %d independent pairs per GPU and step"
+                                   " (configs[2] = the same pairs at 32 per GPU over 8 GPUs: --gpus 8 --pairs-per-gpu 32)"
+                                   % (args.scan_points, args.map_points, args.optimizer, n_local),
                        "pairs_per_gpu": n_local, "batches_in_flight": S, "schedule": args.schedule, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
+                       "flags": args.flags, "plane_memo_within_one_align": not (args.flags & 16), "search_kernel": "legacy per-cell" if (args.flags & 8) else "flat lists",
                        "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_linearize", "avg_launch_ms": avg_launch_ms,
-                         "algorithmic_bytes_per_point_pass": b_pi, "candidates_per_point": kbar, "slots_probed_per_point": probes,
-                         "point_passes_per_launch": st["point_passes"] * share / timed, "launches": launches, "launches_timed": st["timed_launches"],
-                         "tiles_on_lds_grid": sc["tiles_lds_grid"] / max(1, sc["tiles"]), "tiles_staged_through_lds": sc["tiles_lds_points"] / max(1, sc["tiles"]),
-                         "residual_kernel_avg_ms": (st["residual_ms"] / launches) if st["residual_ms"] > 0 else None},
+            "roofline": roof,
         }
         # the CPU leg is timed on rank 0 of the single-GPU run only (the other ranks would idle behind it)
         out["cpu_baseline"] = None
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"], oracle_results = cpu_baseline(pairs, cfg, args.cpu_seconds)
             out["config"].update(full_size_parity(res, oracle_results))   # untimed: the timed GPU poses against the oracle's, full size
+            one, _ = cpu_baseline(pairs[:3], cfg, min(15.0, args.cpu_seconds), threads=1)
+            out["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
     if world > 1:
         dist.barrier(**bar_kw)
         dist.destroy_process_group()

@@ -39,7 +39,8 @@ typedef enum pcm_status {
   PCM_ERR_HIP = -3,            /* a HIP runtime call failed; see pcm_last_error */
   PCM_ERR_UNSUPPORTED = -4,
   PCM_ERR_OUT_OF_RANGE = -5,   /* voxel coordinate outside +-2^20 cells */
-  PCM_ERR_NOT_CONVERGED = -6   /* "lm not converged!!"  impl/lsq_registration_impl.hpp:69-72 (result still written) */
+  PCM_ERR_NOT_CONVERGED = -6,  /* "lm not converged!!"  impl/lsq_registration_impl.hpp:69-72 (result still written) */
+  PCM_ERR_INTERNAL = -7        /* a pair of a batch was not driven to the end of its loop (library bug); its pose is not a result */
 } pcm_status;
 
 /* residual models */
@@ -95,7 +96,7 @@ typedef struct pcm_config {
   int32_t k_correspondences;     /* 20  impl/fast_gicp_impl.hpp:16 */
   int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
   int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
-  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics */
+  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 and 3-4 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics */
   int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
   float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
@@ -113,6 +114,12 @@ typedef struct pcm_config {
  * `p_body.norm() > 81 pd2^2` test keeps its flag and contributes the residual an earlier call -- possibly of an older frame --
  * stored for its index; a point never stored contributes 0).  Set it before pcm_set_source of the first scan.  Off (default):
  * such a point is dropped for that call, the result depends on the current scan, map and state only. */
+#define PCM_FLAG_LEGACY_SEARCH 8     /* P2PLANE: the round-2 search kernel (27 cells walked one after the other, one plane fit per lane) instead of
+                                     * k_linearize_flat; same neighbour lists, planes and sums -- A/B switch, never changes a result */
+#define PCM_FLAG_NO_PLANE_MEMO 16   /* k_linearize_flat: fit every plane in every linearize pass.  Default (off): inside ONE align a point whose five
+                                     * neighbours are those of the previous pass, in the same order, re-uses that pass's plane -- esti_plane
+                                     * (common_lib.h:186-243) sees the ordered neighbour tuple only, so the plane is the same bits; the memo is
+                                     * never read in the first pass of an align and never survives one */
 #define PCM_FLAG_FUSED_STEP 2       /* GN: take the step in the search kernel's last workgroup (write-through hand-off of the partial rows) instead of
                                      * a second launch; same sums in the same order; measured slower at every round size, off by default */
 

@@ -64,6 +64,8 @@ def lib():
         L.orc_obs_model.argtypes = [C.c_void_p, C.POINTER(LioState), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_set_neighbor_radius.argtypes = [C.c_void_p, C.c_double]
         L.orc_set_neighbor_radius.restype = None
+        L.orc_set_knn_order.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_knn_order.restype = None
         L.orc_set_lio_reference_semantics.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_lio_reference_semantics.restype = None
         L.orc_get_lio_members.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
@@ -193,6 +195,11 @@ class Oracle:
     def set_neighbor_radius(self, radius):
         """NeighborSearchMethod::DIRECT_RADIUS of the CUDA-core models (radius in voxels; 0 = off)."""
         lib().orc_set_neighbor_radius(self._h, float(radius))
+
+    def set_knn_order(self, order="ascending"):
+        """Row order of the neighbours handed to esti_plane: "ascending" (default, the HIP kernels' order) or "libstdcxx"
+        (what the reference's three std::nth_element calls leave with the container's libstdc++)."""
+        lib().orc_set_knn_order(self._h, {"ascending": 0, "libstdcxx": 1}[order])
 
     def set_lio_reference_semantics(self, on=True):
         """Keep residuals_/point_selected_surf_/plane_coef_ across calls and frames as LaserMapping's members do."""

@@ -51,6 +51,7 @@ typedef struct oracle {
    * in the reference-semantics mode of orc_obs_model */
   double nb_radius;            /* > 0: NeighborSearchMethod::DIRECT_RADIUS (orc_set_neighbor_radius) */
   int lio_ref;                 /* orc_set_lio_reference_semantics */
+  int knn_order;               /* orc_set_knn_order: ORC_KNN_ORDER_* */
   float *ref_plane;            /* plane_coef_           [ref_n][4] */
   float *ref_resid;            /* residuals_            [ref_n]    */
   unsigned char *ref_sel;      /* point_selected_surf_  [ref_n]    */

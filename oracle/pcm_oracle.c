@@ -200,9 +200,13 @@ static void sort_distpts(orc_distpt *c, int n) {
 /*
  * IVox::GetClosestPoint(pt, closest, max_num, max_range)  ivox3d.h:132-204 with
  * IVoxNode::KNNPointByCondition  ivox3d_node.hpp:140-205.
- * Output: up to K target indices, ascending distance (the reference only
- * guarantees the minimum at the front; the SET is what matters).
+ * Output: up to K target indices.  ORC_KNN_ORDER_ASCENDING (default, what the HIP kernels produce): ascending distance,
+ * equal distances in visit order.  ORC_KNN_ORDER_LIBSTDCXX: the order the reference's three std::nth_element calls leave
+ * with libstdc++ (orc_knn_libstdcxx.cpp) -- the row order of the matrix esti_plane factorises, which moves the float plane
+ * fit at rounding level (tests/test_knn_order.py measures by how much).
  */
+void orc_std_nth_element(orc_distpt *first, int nth, int n);
+void orc_set_knn_order(void *h, int order) { ((oracle *)h)->knn_order = order; }
 int orc_ivox_knn(const oracle *o, const float q[3], int *idx_out, float *d2_out, orc_distpt_buf *buf) {
   const orc_ivox *v = &o->tgt_ivox;
   const int K = o->cfg.knn;
@@ -233,12 +237,22 @@ int orc_ivox_knn(const oracle *o, const float q[3], int *idx_out, float *d2_out,
         n++;
       }
     }
-    keep_k_smallest(cand, old, &n, K); /* per-voxel nth_element + resize */
+    if (o->knn_order == ORC_KNN_ORDER_LIBSTDCXX) {   /* ivox3d_node.hpp:176-181 */
+      if (n - old > K) { orc_std_nth_element(cand + old, K - 1, n - old); n = old + K; }
+    } else {
+      keep_k_smallest(cand, old, &n, K); /* per-voxel nth_element + resize */
+    }
   }
   if (n == 0) return 0;
-  int lo = 0;
-  keep_k_smallest(cand, lo, &n, K);
-  sort_distpts(cand, n);
+  if (o->knn_order == ORC_KNN_ORDER_LIBSTDCXX) {
+    /* ivox3d.h:173-178, on the container's libstdc++ (orc_knn_libstdcxx.cpp) */
+    if (n > K) { orc_std_nth_element(cand, K - 1, n); n = K; }
+    orc_std_nth_element(cand, 0, n);
+  } else {
+    int lo = 0;
+    keep_k_smallest(cand, lo, &n, K);
+    sort_distpts(cand, n);
+  }
   for (int i = 0; i < n; i++) {
     idx_out[i] = cand[i].idx;
     if (d2_out) d2_out[i] = (float)cand[i].dist;

@@ -119,6 +119,11 @@ int orc_obs_model(void *h, const orc_lio_state *s, int extrinsic_est_en, int con
  * fails the 81 pd2^2 test stays selected and contributes the residual stored for its index by an earlier call).
  * on == 0 (default): the clean semantics of SURVEY a14 -- such a point is dropped for that call. */
 void orc_set_lio_reference_semantics(void *h, int on);
+/* order of the <= 5 neighbours handed to esti_plane: ascending distance (default; the HIP kernels' order) or the order libstdc++'s
+ * std::nth_element leaves in IVox::GetClosestPoint (ivox3d.h:173-178, ivox3d_node.hpp:176-181) */
+#define ORC_KNN_ORDER_ASCENDING 0
+#define ORC_KNN_ORDER_LIBSTDCXX 1
+void orc_set_knn_order(void *h, int order);
 /* NDT_P2D / NDT_D2D / VGICP_CUDA: radius > 0 selects NeighborSearchMethod::DIRECT_RADIUS (voxel offsets with |offset| <= radius + 1e-3,
  * src/fast_gicp/cuda/ndt_cuda.cu:70-83, fast_vgicp_cuda.cu:77-90); 0 returns to the DIRECT1 / 7 / 27 tables */
 void orc_set_neighbor_radius(void *h, double radius);

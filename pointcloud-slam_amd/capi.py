@@ -21,8 +21,11 @@ PCM_ABI_VERSION = 2   # include/pcm_amd.h
 PCM_OK = 0
 PCM_FLAG_NO_LDS_STAGING = 1
 PCM_FLAG_FUSED_STEP = 2
+PCM_FLAG_LEGACY_SEARCH = 8            # round-2 search kernel (A/B)
+PCM_FLAG_NO_PLANE_MEMO = 16           # fit every plane in every pass (A/B)
 PCM_FLAG_LIO_REFERENCE_SEMANTICS = 4   # pcm_obs_model keeps LaserMapping's per-point members across calls and scans
 PCM_ERR_NOT_CONVERGED = -6
+PCM_ERR_INTERNAL = -7
 MEM_HOST, MEM_DEVICE = 0, 1
 MODEL = {"P2PLANE": 0, "GICP": 1, "VGICP": 2, "NDT_P2D": 3, "NDT_D2D": 4, "NDT_OMP": 5, "VGICP_CUDA": 6}
 OPTIMIZER = {"GN": 0, "LM": 1}

@@ -367,8 +367,10 @@ int prepare(pcm_ctx* c) {
   }
   if (c->planes_cap < c->src.n) {
     if (c->planes) hipFree(c->planes);
-    c->planes = nullptr; c->planes_cap = 0;
+    if (c->fitcache) hipFree(c->fitcache);
+    c->planes = nullptr; c->fitcache = nullptr; c->planes_cap = 0;
     HIPCK(c, hipMalloc(&c->planes, sizeof(float4) * c->src.n));
+    HIPCK(c, hipMalloc(&c->fitcache, sizeof(float4) * c->src.n));
     c->planes_cap = c->src.n;
   }
   return PCM_OK;
@@ -416,6 +418,7 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->corr = c->corr;
   d->nn = c->nn;
   d->planes = c->planes;
+  d->fitcache = c->fitcache;
   d->partials = partials;
   d->counter = c->counter;
 }
@@ -440,6 +443,7 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.points_per_block = geom.points_per_block;
   kp.tiles_per_pair = geom.tiles_per_pair;
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
+  kp.plane_cache = (g.flags & PCM_FLAG_NO_PLANE_MEMO) ? 0 : 1;
   kp.do_step = 1;
   kp.lin_points_per_block = (is_ndt(g.model) || g.model == PCM_MODEL_VGICP_CUDA) ? geom.points_per_block : 256;
   kp.coord_mode = coord_mode_for(g.model);
@@ -528,7 +532,12 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   // simply never launched before).  Every round then carries about `window` live pairs, so the fixed cost of a round (two launches,
   // their boundaries) is shared by that many registrations for the whole batch, not only in its first rounds.  No device-side hand-off.
   const bool host_window = window < n && n <= 256 && window <= kMaxListedPairs;
-  const int max_rounds = host_window ? per_pair_rounds * ((n + window - 1) / window + 1) + 4
+  // Round budget.  Host window: a slot serves its pairs one after the other, and every hand-over costs one extra round because the
+  // status bytes are read one round behind; with every pair running to max_iterations a slot needs ceil(n / window) * (rounds + 1)
+  // rounds, one more pair's worth covers an uneven hand-out (round-2 advisor finding: the old bound ran out for 256 pairs at a
+  // window of 8 and 10 GN iterations and returned unfinished pairs as PCM_OK).  A pair the loop leaves unfinished is reported
+  // with PCM_ERR_INTERNAL by k_pack_results, never silently.
+  const int max_rounds = host_window ? ((n + window - 1) / window + 1) * (per_pair_rounds + 1) + 2
                                      : per_pair_rounds * (n - window + 1) + 1 + 2 * (n - window);   // + the rounds a handed-over pair spends PENDING
   const size_t per_pair_partials = (size_t)std::max(geom.blocks_per_pair, geom.tiles_per_pair) * kPartialStride;
   Workspace* w = nullptr;
@@ -569,6 +578,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 16, st));
   const bool is_lm = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;
   const bool write_sel = is_lm;  // trial passes re-use the planes of the selected set
+  const bool legacy_search = (g.flags & PCM_FLAG_LEGACY_SEARCH) != 0;   // the round-2 per-cell search kernel (A/B)
 
   int rounds_done = 0;
   size_t prof_used = 0;
@@ -604,6 +614,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), false);
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
+    else if (!legacy_search) launch_linearize_flat(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (timed) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
     if (!fuse) launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
@@ -682,10 +693,11 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   int worst = PCM_OK;
   for (int i = 0; i < n; i++) {
     passes += (uint64_t)(h_res[i].num_linearize + h_res[i].num_compute_error) * num_elements(ctxs[i]);
-    if (h_res[i].status != PCM_OK) worst = h_res[i].status;
+    if (h_res[i].status != PCM_OK && worst != PCM_ERR_INTERNAL) worst = h_res[i].status;
   }
   c0->stats.point_passes += passes;
-  if (worst != PCM_OK) c0->err = "lm not converged!!";
+  if (worst == PCM_ERR_INTERNAL) c0->err = "the round budget of the batch ran out before every pair finished (library bug): unfinished pairs carry PCM_ERR_INTERNAL";
+  else if (worst != PCM_OK) c0->err = "lm not converged!!";
   return worst;
 }
 
@@ -713,6 +725,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
   if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, ndt_kind(c->cfg.model), !linearize);
   else if (is_gicp(c->cfg.model)) launch_gicp(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_VGICP, !linearize);
+  else if (linearize && !(c->cfg.flags & PCM_FLAG_LEGACY_SEARCH)) launch_linearize_flat(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
   launch_finish_round(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, !linearize, false, w->d_flags, w->d_sums);
@@ -998,6 +1011,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->ndt_out) hipFree(c->ndt_out);
     if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
     if (c->planes) hipFree(c->planes);
+    if (c->fitcache) hipFree(c->fitcache);
     if (c->counter) hipFree(c->counter);
     if (c->nn) hipFree(c->nn);
     free_ws(c);

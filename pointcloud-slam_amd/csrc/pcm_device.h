@@ -4,8 +4,8 @@
 //   pts        float4[M]      map points grouped by voxel; voxels grouped by 8x8x8
 //                             BRICK (brick-major, then z-fastest inside the brick), so
 //                             all points of a brick are ONE contiguous run; .w carries
-//                             the voxel tag (brick slot << 9 | voxel-in-brick) as raw
-//                             int bits: equal tags <=> same voxel
+//                             the voxel-in-brick index (bits 0..8) as raw int bits, and on
+//                             the first point of a voxel bit 31 + the voxel's point count
 //   vox_start  uint32[V+1]    first point of every occupied voxel, same order
 //   bricks     BrickSlot[cap] linear-probed hash of the occupied bricks (cap = pow2 >=
 //                             4 x #bricks); the reference's CUDA bucket is one
@@ -38,7 +38,8 @@ struct BrickSlot {
   uint32_t pad[2];
 };
 static_assert(sizeof(BrickSlot) == 32, "BrickSlot must be 32 bytes");
-constexpr uint32_t kMaxBrickSlots = 1u << 22;  // slot index must fit the 22 tag bits of pts.w
+constexpr uint32_t kMaxBrickSlots = 1u << 22;
+constexpr uint32_t kMaxTagCount = (1u << 22) - 1u;   // points of a voxel as its head point's tag carries them (bits 9..30 of pts.w)
 
 __host__ __device__ inline uint64_t pack_brick(int bx, int by, int bz) {
   return ((uint64_t)(uint32_t)(bx + kBrickBias) << 36) | ((uint64_t)(uint32_t)(by + kBrickBias) << 18) | (uint64_t)(uint32_t)(bz + kBrickBias);
@@ -194,8 +195,9 @@ struct PairDesc {
   TargetView tgt;
   SourceView src;
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
+  float4* fitcache;     // N: plane memo of k_linearize_flat: esti_plane's result for the neighbour tuple kept in nn (x = NaN: rejected)
   LioPose lio;          // LIO measurement model only
-  uint32_t* nn;         // LIO: [N][5] neighbour indices into tgt.pts (~0u: none) from the last matching call
+  uint32_t* nn;         // LIO: [N][5] neighbour indices into tgt.pts (~0u: none) from the last matching call; P2PLANE: the tuple of the plane memo
   float2* lio_aux;      // LIO reference semantics: residuals_[i] (.x) and point_selected_surf_[i] (.y != 0) in the caller's scan order
   int32_t* corr;        // NDT / VGICP: [elements][offsets] matched target voxel (or -1) of the last linearize; GICP: [N] matched target point
   const double* src_cov;   // GICP / VGICP: [N][6] regularised covariance of every source point (xx xy xz yy yz zz)
@@ -249,6 +251,8 @@ struct KernelParams {
   int32_t use_list;           // 1: the grid's pair axis indexes `active` (only pairs the host still believes active are launched)
   uint8_t active[kMaxListedPairs];   // pair index of each grid entry (batches of <= kMaxListedPairs pairs; indices < 256)
   double max_corr_sq;         // GICP: corr_dist_threshold_^2 (double, as pcl::Registration holds it)
+  int32_t plane_cache;        // k_linearize_flat: 1 = memoise the plane of a point's ordered neighbour tuple across the linearize passes of one align
+  int32_t pad_kp;
 };
 
 }  // namespace pcm

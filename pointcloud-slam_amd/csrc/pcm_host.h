@@ -104,6 +104,8 @@ struct LaunchGeom {
 };
 void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                       unsigned long long* d_stats, bool timing);
+void launch_linearize_flat(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
+                           unsigned long long* d_stats, bool timing = false);
 void launch_linearize_fused(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, unsigned char* d_flags_row);
 void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp);
 void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out);
@@ -166,6 +168,7 @@ struct pcm_ctx {
   size_t src_order_cap = 0;
   bool src_sorted = false;       // src_order holds the current source
   float4* planes = nullptr;
+  float4* fitcache = nullptr;    // plane memo of k_linearize_flat (with nn), same capacity as planes
   unsigned int* counter = nullptr;   // round tickets (device, one word)
   size_t planes_cap = 0;
   std::string err;

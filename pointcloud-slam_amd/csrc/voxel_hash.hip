@@ -119,20 +119,20 @@ __global__ void k_finalize_bricks(BrickSlot* __restrict__ slots, const uint32_t*
   }
 }
 
-// points into sorted order, tagged with (voxel-head bit << 31 | brick slot << 9 | voxel-in-brick)
-__global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ keys, uint32_t n,
-                                const BrickSlot* __restrict__ slots, uint32_t mask, float4* __restrict__ out) {
+// points into sorted order, tagged in .w (raw bits): voxel-in-brick in bits 0..8; the FIRST point of a voxel's run also carries
+// bit 31 and, in bits 9..30, the number of points of its voxel (clamped to kMaxTagCount) -- a reader of a staged brick finds the
+// voxel heads and the length of every voxel's run without comparing neighbouring tags or walking to the next head
+__global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* __restrict__ idx, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vrank,
+                                const uint32_t* __restrict__ vox_start, uint32_t n, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint64_t bkey = keys[i] >> 9;
-  const int bx = (int)(bkey >> 36) - kBrickBias, by = (int)((bkey >> 18) & 0x3ffff) - kBrickBias, bz = (int)(bkey & 0x3ffff) - kBrickBias;
-  uint32_t h = hash_coord(bx, by, bz) & mask;
-  while (slots[h].key != bkey) h = (h + 1) & mask;
   float4 p = in[idx[i]];
-  // bit 31 marks the first point of a voxel's run, so a reader of a staged run finds voxel heads and run ends without
-  // comparing neighbouring tags (the slot index fits bits 9..30: kMaxBrickSlots)
-  const uint32_t head = (i == 0 || keys[i - 1] != keys[i]) ? 0x80000000u : 0u;
-  p.w = __int_as_float((int)(head | (h << 9) | (uint32_t)(keys[i] & 511u)));
+  uint32_t tag = (uint32_t)(keys[i] & 511u);
+  if (i == 0 || keys[i - 1] != keys[i]) {   // vrank = exclusive scan of the head flags: at a head it is the voxel's index
+    const uint32_t cnt = vox_start[vrank[i] + 1u] - i;
+    tag |= 0x80000000u | ((cnt < kMaxTagCount ? cnt : kMaxTagCount) << 9);
+  }
+  p.w = __int_as_float((int)tag);
   out[i] = p;
 }
 
@@ -327,7 +327,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     }
     uint32_t cap = 1024;
     while (cap < 4ull * nbricks) cap <<= 1;
-    if (cap > kMaxBrickSlots) { *err = "too many occupied bricks for the 22-bit voxel tag"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
+    if (cap > kMaxBrickSlots) { *err = "too many occupied bricks"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
     CK(hipMalloc(&map->bricks, sizeof(BrickSlot) * (size_t)cap));
     CK(hipMalloc(&map->bmask, sizeof(uint32_t) * 16 * (size_t)cap));
     CK(hipMalloc(&map->bpref, sizeof(uint16_t) * 16 * (size_t)cap));
@@ -342,7 +342,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     CK(hipGetLastError());
     k_finalize_bricks<<<cdiv(cap, 256), 256, 0, stream>>>(map->bricks, map->bmask, map->bpref, map->vox_start, cap);
     CK(hipGetLastError());
-    k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, keys_s, n, map->bricks, cap - 1, map->pts);
+    k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, keys_s, vrank, map->vox_start, n, map->pts);
     CK(hipGetLastError());
     if (want_gauss) {
       CK(hipMalloc(&map->gvox, sizeof(GaussVoxel) * ((size_t)nvox + 1)));

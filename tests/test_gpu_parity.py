@@ -342,3 +342,24 @@ def test_host_window_equals_singles(pcm, synth, optimizer):
             s, b = singles[k % len(base)], batch[k]
             assert np.array_equal(s.T64, b.T64) and s.iterations == b.iterations and s.num_linearize == b.num_linearize, (window, k)
             assert s.num_compute_error == b.num_compute_error and s.converged == b.converged
+
+
+@pytest.mark.parametrize("window,n,max_it", [(1, 24, 3), (2, 60, 5), (8, 100, 5)])
+def test_host_window_with_pairs_that_never_converge(pcm, synth, window, n, max_it):
+    """Round budget of the host-kept window (round-2 advisor finding): with every pair running to max_iterations each slot
+    hand-over costs one stale round on top; the old budget ran out and returned unfinished pairs as PCM_OK.  Every pair must
+    come back finished (status OK, max_it iterations, the pose it gets alone)."""
+    base = [synth.make_pair(120 + i, 700 + 90 * i, 7000 + 900 * i) for i in range(4)]
+    regs, guesses = [], []
+    for k in range(n):
+        p = base[k % len(base)]
+        g = pcm.P2PlaneRegistration(0, optimizer="GN", batch_window=window, max_iterations=max_it, rotation_eps=1e-12, translation_eps=1e-12)
+        g.set_input_target(p.submap); g.set_input_source(p.scan)
+        regs.append(g); guesses.append(p.guess)
+    batch = pcm.align_batch(regs, np.stack(guesses))
+    singles = [regs[k].align(base[k].guess) for k in range(len(base))]
+    for k in range(n):
+        s, b = singles[k % len(base)], batch[k]
+        # nr_iterations_ = index of the last iteration (lsq_registration_impl.hpp:63-64)
+        assert b.status == 0 and not b.converged and b.iterations == max_it - 1 and b.num_linearize == max_it, (k, b.status, b.iterations)
+        assert np.array_equal(s.T64, b.T64)

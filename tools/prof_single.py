@@ -41,5 +41,5 @@ if a.phases:
     res = pcm.align_batch(regs, g)
     pc = regs[0].phase_cycles()
     n = max(1, pc[7])
-    names = ['load+box', 'probe', 'stage', 'cellgrid', 'search', 'fit', 'jobs+residual+reduce']
+    names = ['load+box', 'probe', 'stage', 'cellgrid', 'search', 'fit', 'jobs+residual+reduce'] if (a.flags & 8) else ['load+box', 'probe', 'stage+grid', 'lists', 'search', 'memo+fits', 'store+residual+reduce']
     print('tiles', pc[7]); print({k: round(v / n) for k, v in zip(names, pc[:7])}, 'ticks/tile')
