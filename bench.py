@@ -281,7 +281,13 @@ def main():
     def run_steps(k, stagger_s=0.0):
         """k passes over the batch; returns the results of the last one (sharding.run_rotating_steps / run_pipelined_steps:
         slot threads for the compute, one thread for the collectives)."""
-        kw = dict(on_thread_start=lambda: torch.cuda.set_device(dev_index))
+        def fail_fast(exc):
+            # this rank cannot issue its remaining collectives: end the process, so the peers fail on a closed connection instead of
+            # waiting in their all-gather for the backend's timeout
+            sys.stderr.write("rank %d: %r -- aborting the job\n" % (rank, exc))
+            sys.stderr.flush()
+            os._exit(13)
+        kw = dict(on_thread_start=lambda: torch.cuda.set_device(dev_index), on_error=fail_fast if world > 1 else None)
         if rotate:
             return sharding.run_rotating_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s, **kw)
         last = sharding.run_pipelined_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s, **kw)

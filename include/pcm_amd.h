@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PCM_ABI_VERSION 2
+#define PCM_ABI_VERSION 3
 
 typedef enum pcm_status {
   PCM_OK = 0,
@@ -96,7 +96,7 @@ typedef struct pcm_config {
   int32_t k_correspondences;     /* 20  impl/fast_gicp_impl.hpp:16 */
   int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
   int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
-  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 and 3-4 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics */
+  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 and 3-4 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics, bit 5 the neighbour row order */
   int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
   float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
@@ -120,6 +120,13 @@ typedef struct pcm_config {
                                      * neighbours are those of the previous pass, in the same order, re-uses that pass's plane -- esti_plane
                                      * (common_lib.h:186-243) sees the ordered neighbour tuple only, so the plane is the same bits; the memo is
                                      * never read in the first pass of an align and never survives one */
+#define PCM_FLAG_REFERENCE_KNN_ORDER 32
+/* P2PLANE align / linearize: hand esti_plane its neighbours in the row order the reference's IVox::GetClosestPoint leaves -- the
+ * order of libstdc++'s std::nth_element (jueying_lio/include/ivox3d/ivox3d.h:173-178, ivox3d_node.hpp:176-181) -- instead of
+ * ascending distance.  Same neighbour set; the float plane fit of a row-permuted system rounds differently (measured on the
+ * bench pairs: ~17 % of the planes differ in the last bits, poses by up to 8e-5 m when an LM iteration count flips;
+ * profiles/r03_knn_order_sensitivity.json).  Compatibility mode: a slower kernel (private candidate array per scan point, no LDS
+ * staging), maps with at most 121 points per voxel (PCM_ERR_UNSUPPORTED beyond); pcm_obs_model does not take it. */
 #define PCM_FLAG_FUSED_STEP 2       /* GN: take the step in the search kernel's last workgroup (write-through hand-off of the partial rows) instead of
                                      * a second launch; same sums in the same order; measured slower at every round size, off by default */
 
@@ -154,6 +161,8 @@ typedef struct pcm_stats {
   uint64_t timed_launches;       /* launches bracketed by HIP events (= linearize_launches unless profiling bit3 samples them) */
   uint64_t timed_pair_slots;     /* sum of the pair-list lengths of the timed launches ... */
   uint64_t launched_pair_slots;  /* ... and of all launches: the share of point_passes that falls to the timed ones */
+  uint64_t planes_wanted;        /* point passes with exactly five neighbours, i.e. a float plane fit is due (counter passes only) */
+  uint64_t planes_fitted;        /* ... of which the plane memo did not answer: fits actually run */
 } pcm_stats;
 
 typedef struct pcm_ctx pcm_ctx;
@@ -214,8 +223,12 @@ int pcm_get_lio_members(pcm_ctx *ctx, float *residuals, uint8_t *selected, size_
  * rematch = ekfom_data.converge: non-zero -> 5-NN + plane fit for every scan point;
  * zero -> the planes of the previous call are re-used (laser_mapping.cc:616).
  * Target = the map (pcm_set_target), source = the down-sampled scan in the LiDAR frame.
- * One documented difference: a point failing the ||p|| > 81 pd2^2 test is dropped for
- * this call (the reference keeps a stale residual, laser_mapping.cc:632-635). */
+ * Two semantics for a selected point that fails the ||p|| > 81 pd2^2 test (laser_mapping.cc:631-635):
+ *   default                           -- the point is dropped for this call (a function of scan, map and state only);
+ *   PCM_FLAG_LIO_REFERENCE_SEMANTICS  -- the reference's: point_selected_surf_[i] stays set and the row carries the residual an
+ *                                        earlier call (of this frame or of an older one, by index) stored in residuals_[i];
+ *                                        both members persist across calls and scans with std::vector::resize semantics
+ *                                        (laser_mapping.cc:335-339).  Parity hook: pcm_get_lio_members. */
 typedef struct pcm_lio_state {
   double rot[4];     /* s.rot            world <- imu */
   double pos[3];     /* s.pos */

@@ -221,7 +221,8 @@ public:
 
 namespace detail {
 // setNeighborSearchMethod(method, radius) of the CUDA-core classes (ndt_cuda_impl.hpp:30-32, fast_vgicp_cuda_impl.hpp:59-61):
-// DIRECT_RADIUS takes the radius in voxels (ndt_cuda.cu:70-83); the other methods ignore it
+// DIRECT_RADIUS takes the radius in voxels (ndt_cuda.cu:70-83); the other methods ignore it.  Against the reference: the radius
+// is stored as a float and must lie in (0, 3] voxels (align() returns PCM_ERR_INVALID_ARGUMENT beyond; the reference accepts any double)
 inline void set_search_method(pcm_config& cfg, NeighborSearchMethod m, double radius) {
   cfg.neighbor_search_radius = 0.f;
   if (m == NeighborSearchMethod::DIRECT_RADIUS) cfg.neighbor_search_radius = static_cast<float>(radius);

@@ -17,11 +17,12 @@ SYMBOLS = [
     "pcm_get_stats", "pcm_reset_stats",
 ]
 
-PCM_ABI_VERSION = 2   # include/pcm_amd.h
+PCM_ABI_VERSION = 3   # include/pcm_amd.h
 PCM_OK = 0
 PCM_FLAG_NO_LDS_STAGING = 1
 PCM_FLAG_FUSED_STEP = 2
 PCM_FLAG_LEGACY_SEARCH = 8            # round-2 search kernel (A/B)
+PCM_FLAG_REFERENCE_KNN_ORDER = 32      # neighbours in the order of libstdc++'s std::nth_element (the reference's), slower kernel
 PCM_FLAG_NO_PLANE_MEMO = 16           # fit every plane in every pass (A/B)
 PCM_FLAG_LIO_REFERENCE_SEMANTICS = 4   # pcm_obs_model keeps LaserMapping's per-point members across calls and scans
 PCM_ERR_NOT_CONVERGED = -6
@@ -70,7 +71,8 @@ class PcmStats(C.Structure):
                 ("candidates", C.c_uint64), ("slots_probed", C.c_uint64), ("linearize_ms", C.c_double),
                 ("target_voxels", C.c_uint64), ("target_slots", C.c_uint64), ("tiles", C.c_uint64),
                 ("tiles_lds_grid", C.c_uint64), ("tiles_lds_points", C.c_uint64), ("residual_ms", C.c_double),
-                ("timed_launches", C.c_uint64), ("timed_pair_slots", C.c_uint64), ("launched_pair_slots", C.c_uint64)]
+                ("timed_launches", C.c_uint64), ("timed_pair_slots", C.c_uint64), ("launched_pair_slots", C.c_uint64),
+                ("planes_wanted", C.c_uint64), ("planes_fitted", C.c_uint64)]
 
 
 def library_path() -> str:

@@ -41,14 +41,13 @@
 namespace pcm {
 
 // ---------------------------------------------------------------------------
-// End of a round, one 1024-thread workgroup per pair: fixed-order sum of the
-// round's partial rows (deterministic: 32 row groups x 32 columns, then a serial
-// sum of the 32 group totals) + the GN/LM state machine, or the export of the
-// sums for the parity hooks.  The pair's status byte for this round goes straight
-// to mapped pinned host memory (a posted write), which is all the host polls.
-// (Doing this in the last-arriving workgroup of the residual kernel was tried and
-// lost: the per-workgroup agent-scope release fence cost more than this launch.)
-// grid = npairs, block = 1024
+// End of a round, one 256-thread workgroup per pair (k_finish_round below): fixed-order sum of the round's partial rows
+// (deterministic: 32 row groups of stride 32, each summed in row order, four groups per thread advancing together; then the
+// group totals in group order) + the GN/LM state machine on an LDS copy of the pair's state, or the export of the sums for the
+// parity hooks.  The pair's status byte for this round goes straight to mapped pinned host memory (a posted write), which is
+// all the host polls.  (Doing this in the last-arriving workgroup of the residual kernel -- PCM_FLAG_FUSED_STEP -- is kept as an
+// option and measured slower: every workgroup pays a store drain and a returned atomic.)
+// grid = npairs, block = 256
 // ---------------------------------------------------------------------------
 __device__ inline void unpack_sums(const double* s, double* H, double* b, double* cost, int* inliers) {
   int t = 0;

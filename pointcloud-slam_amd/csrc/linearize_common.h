@@ -196,4 +196,57 @@ __device__ inline int wave_max_i32(int x) {
   return __builtin_amdgcn_readlane(x, 63);
 }
 
+// ---- tail of a linearize tile: residual / Jacobian row of every lane -> 29 sums of the tile -> one partial row.
+// e = n.(T p) + d (laser_mapping.cc:627-629), valid iff |p_body| > 81 e^2 (:631), left-perturbation Jacobian [ (q x n)^T , n^T ];
+// products formed in double from the float values like h_x (esekfom.hpp:1687), 8 groups of 32 rows each summed in row order, then
+// the groups in order: the fixed order k_finish_round continues.  All 256 threads call it; `smem` is 16-byte aligned LDS of at
+// least kReduceLdsBytes that nobody else touches any more (the caller's last barrier lies behind every other use); two barriers inside.
+constexpr int kReduceLdsBytes = 256 * 8 * 8 + 8 * kPartialStride * 8;
+template <bool WRITE_PLANES>
+__device__ inline void residual_and_reduce(const PairDesc& d, uint32_t i, uint32_t tile_x, bool live, const float4& pl, const float (&q)[3], float pn_body, void* smem) {
+  double* const s_row = reinterpret_cast<double*>(smem);   // [256][8]: J0..J5, e, selected
+  double* const s_grp = s_row + 256 * 8;                   // [8][32] group partials
+  {
+    float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      bool sel = !(pl.x != pl.x);
+      if (sel) {
+        const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;
+        sel = pn_body > 81.f * pd2 * pd2;
+        if (sel) {
+          row[0] = q[1] * pl.z - q[2] * pl.y;
+          row[1] = q[2] * pl.x - q[0] * pl.z;
+          row[2] = q[0] * pl.y - q[1] * pl.x;
+          row[3] = pl.x; row[4] = pl.y; row[5] = pl.z;
+          row[6] = pd2;
+          row[7] = 1.f;
+        }
+      }
+      if (WRITE_PLANES) gstore4(d.planes + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
+    }
+    double2* dst = reinterpret_cast<double2*>(s_row + threadIdx.x * 8);
+#pragma unroll
+    for (int a = 0; a < 4; a++) dst[a] = make_double2((double)row[2 * a], (double)row[2 * a + 1]);
+  }
+  __syncthreads();
+  {
+    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double v = 0.0;
+    if (j < kNumSums) {
+      const int ia = c_term_a[j], ib = c_term_b[j];
+      const double* r0 = s_row + (g * 32) * 8;
+#pragma unroll 8
+      for (int k = 0; k < 32; k++) v = fma(r0[k * 8 + ia], r0[k * 8 + ib], v);
+    }
+    s_grp[g * kPartialStride + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums) {
+    double v = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
+    gstore_d(d.partials + (size_t)tile_x * kPartialStride + threadIdx.x, v);
+  }
+}
+
 }  // namespace pcm

@@ -38,30 +38,24 @@
 
 namespace pcm {
 
-constexpr int kFCapCells = 2048;     // LDS voxel grid of a tile
-constexpr int kFCapPts = 1536;       // staged map points per tile; the last slot holds the point at infinity the lists are padded with
+#ifndef PCM_FLAT_WG_PER_CU
+#define PCM_FLAT_WG_PER_CU 4
+#endif
+constexpr int kFCapCells = 2048;     // LDS voxel grid of a tile: one word per cell = first staged point | point count << 16
+#if PCM_FLAT_WG_PER_CU >= 5
+constexpr int kFCapPts = 1216;       // staged map points per tile (5 workgroups per CU: 32 KB each)
+#else
+constexpr int kFCapPts = 1536;
+#endif
 constexpr int kFCapBricks = 64;
-constexpr int kFListCap = 512;       // candidate entries per wave and pass
-constexpr int kFListStride = kFListCap + 8;   // + the look-ahead read behind the last group
-constexpr uint32_t kFPadOff = (uint32_t)(kFCapPts - 1) * 16u;
-constexpr uint16_t kFNoCell = 0xffffu;
-constexpr uint16_t kFOversize = 0xffffu;      // run length marker: the run's list cannot fit, its lanes search the global structures
-// region A of the LDS: cell grid + per-wave lists and run tables while the tile is searched, the fit results afterwards
-constexpr int kFOffCnt = kFCapCells * 2;                      // uint8  s_cnt[kFCapCells]
-constexpr int kFOffList = kFOffCnt + kFCapCells;              // uint16 s_list[4][kFListStride]
-constexpr int kFOffRuns = kFOffList + 4 * kFListStride * 2;   // uint16 s_rcell[4][64], s_rbase[4][64], s_rlen[4][64]
-constexpr int kFRegionA = kFOffRuns + 3 * 4 * 64 * 2;
-static_assert(kFOffList % 8 == 0 && (kFListStride * 2) % 8 == 0, "candidate groups are read as 8-byte words");
-static_assert(256 * 16 <= kFRegionA, "the fit results alias region A");
-static_assert(kFPadOff < 65536u, "list entries are 16-bit byte offsets");
+constexpr int kFBatch = 4;           // candidates of one cell fetched together
+constexpr uint32_t kFMaxCount = 0xffffu;   // points per voxel the cell word can say; a tile that sees more searches the global structures
 
-// one staged point: a 16-byte read (ds_read_b128 is one LDS pass of 4 cycles per wave, the 12-byte form the compiler would
-// pick when .w is unused takes 8)
-__device__ inline float4 lds_point(const char* base, uint32_t off) {
-  float4 v = *reinterpret_cast<const float4*>(base + off);
-  asm volatile("" : "+v"(v.w));
-  return v;
-}
+// one staged point: a 16-byte read (ds_read_b128 is one LDS pass of 4 cycles per wave; the 12-byte form the compiler would pick
+// when .w is unused takes 8).  keep_w() names .w as an input of an empty asm AFTER the points have been consumed, so the
+// wide form is kept without a wait in front of the first use.
+__device__ inline float4 lds_point(const char* base, uint32_t off) { return *reinterpret_cast<const float4*>(base + off); }
+__device__ inline void keep_w(const float4& a, const float4& b, const float4& c, const float4& d) { asm volatile("" ::"v"(a.w), "v"(b.w), "v"(c.w), "v"(d.w)); }
 
 // TIMING (diagnostic build only): lane 0 of every tile stamps s_memtime at the phase boundaries and adds the differences to
 // stats[8..14] (15: tiles); nothing is computed from them.
@@ -73,7 +67,7 @@ __device__ inline float4 lds_point(const char* base, uint32_t off) {
   }
 
 template <bool STATS, bool WRITE_PLANES, bool TIMING = false>
-__global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
+__global__ void __launch_bounds__(256, PCM_FLAT_WG_PER_CU) k_linearize_flat(const PairDesc* __restrict__ descs, const PairState* __restrict__ states, KernelParams kp,
                                                            unsigned long long* __restrict__ stats) {
   // XCD-aware placement as in k_linearize: 8 x 8 transposition inside every run of 64 tiles
   uint32_t tile_x = blockIdx.x;
@@ -93,8 +87,8 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
   const bool memo = kp.plane_cache != 0;
   const bool memo_valid = memo && states[pair].num_linearize > 0;
 
-  __shared__ float4 s_pts[kFCapPts];                       // the bricks' map points; .w = index of the point in the map
-  __shared__ __align__(16) unsigned char s_a[kFRegionA];
+  __shared__ float4 s_pts[kFCapPts + kFBatch];             // the bricks' map points; .w = index of the point in the map (+ the over-read of a batch)
+  __shared__ __align__(16) uint32_t s_cell[kFCapCells];    // cell grid while the tile is searched, the fit results afterwards
   __shared__ uint16_t s_fjob[256][6];                      // queued fits: 5 staged point indices + the neighbour count
   __shared__ int s_red[4][6];
   __shared__ int s_box[8];
@@ -103,10 +97,9 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
   __shared__ uint32_t s_bps[kFCapBricks];
   __shared__ uint32_t s_boff[kFCapBricks + 1];
   __shared__ int s_goff[32];
-  __shared__ uint32_t s_ctr[4];                            // [0] float fits queued, [1] double fits queued, [2] a voxel holds more points than s_cnt can say
-  uint16_t* const s_cell = reinterpret_cast<uint16_t*>(s_a);
-  uint8_t* const s_cnt = s_a + kFOffCnt;
-  float4* const s_fres = reinterpret_cast<float4*>(s_a);   // after the search
+  __shared__ uint32_t s_ctr[4];                            // [0] float fits queued, [1] double fits queued, [2] a voxel holds more points than a cell word can say
+  float4* const s_fres = reinterpret_cast<float4*>(s_cell);   // after the search
+  static_assert(256 * sizeof(float4) <= sizeof(uint32_t) * kFCapCells, "the fit results alias the cell grid");
 
   uint32_t n_cand = 0, n_probe = 0;
   unsigned long long t_prev = 0;
@@ -184,7 +177,6 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
 
   Best best;
   best_init(best, kp.max_range_sq);
-  bool oversize = false;   // this lane's run has more candidates than a list holds
 
   if (use_lds) {
     const int ox0 = s_box[0], oy0 = s_box[1], oz0 = s_box[2];
@@ -217,22 +209,25 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
       if (lane < 27) s_goff[lane] = ((int)c_nearby[lane][0] * Dy + (int)c_nearby[lane][1]) * Dz + (int)c_nearby[lane][2];
     }
     // meanwhile everybody clears the cell grid
+    {   // count 0 = no voxel
+      uint4* g4 = reinterpret_cast<uint4*>(s_cell);
 #pragma unroll
-    for (int j = 0; j < kFCapCells / 256; j++) s_cell[threadIdx.x + 256 * j] = kFNoCell;
+      for (int j = 0; j < kFCapCells / 4 / 256; j++) g4[threadIdx.x + 256 * j] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
     const uint32_t total = s_boff[kFCapBricks];
-    use_lds = total < (uint32_t)kFCapPts;   // still uniform; the last slot is the point at infinity
+    use_lds = total <= (uint32_t)kFCapPts;   // still uniform
     PCMF_STAMP(1)   // brick probes
     if (use_lds) {
       // ---- stage the bricks' map points through LDS: flat, coalesced, all loads in flight ----------
-      float4 v[kFCapPts / 256];
-      int vb[kFCapPts / 256];
+      float4 v[(kFCapPts + 255) / 256];
+      int vb[(kFCapPts + 255) / 256];
+      int b = 0;   // brick of staged point k: k grows with r, so the brick index only moves forward
 #pragma unroll
-      for (int r = 0; r < kFCapPts / 256; r++) {
+      for (int r = 0; r < (kFCapPts + 255) / 256; r++) {
         const uint32_t k = threadIdx.x + 256u * r;
         vb[r] = -1;
         if (k < total) {
-          int b = 0;
           while (b + 1 < nb && s_boff[b + 1] <= k) b++;   // nb is small (typically 1..8)
           vb[r] = b;
           const uint32_t gi = s_bps[b] + (k - s_boff[b]);
@@ -242,7 +237,7 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
       // a voxel head among the staged points (bit 31 of its tag; the tag also carries the voxel's point count) registers its
       // voxel in the cell grid while the points go to LDS; the tag's place is taken by the point's index in the map
 #pragma unroll
-      for (int r = 0; r < kFCapPts / 256; r++) {
+      for (int r = 0; r < (kFCapPts + 255) / 256; r++) {
         const uint32_t k = threadIdx.x + 256u * r;
         if (k < total) {
           const int b = vb[r];
@@ -255,133 +250,59 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
             const int x = o.x + (li >> 6), y = o.y + ((li >> 3) & 7), z = o.z + (li & 7);
             if (x >= 0 && x < Dx && y >= 0 && y < Dy && z >= 0 && z < Dz) {
               const uint32_t cnt = ((uint32_t)tag >> 9) & kMaxTagCount;
-              const int c = (x * Dy + y) * Dz + z;
-              s_cell[c] = (uint16_t)k;
-              s_cnt[c] = (uint8_t)(cnt < 255u ? cnt : 255u);
-              if (cnt > 255u) s_ctr[2] = 1u;
+              s_cell[(x * Dy + y) * Dz + z] = k | ((cnt < kFMaxCount ? cnt : kFMaxCount) << 16);
+              if (cnt > kFMaxCount) s_ctr[2] = 1u;
             }
           }
         }
       }
-      if (threadIdx.x == 0) s_pts[kFCapPts - 1] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __uint_as_float(~0u));
       __syncthreads();
-      use_lds = s_ctr[2] == 0u;   // uniform: a voxel with more than 255 points sends the tile to the global path
+      use_lds = s_ctr[2] == 0u;   // uniform: a voxel with more points than a cell word can say sends the tile to the global path
       PCMF_STAMP(2)   // stage map points + cell grid
     }
-    if (use_lds) {
-      // ---- per wave: runs of lanes with one voxel -> candidate lists -> flat search (no workgroup barrier in here) ----
-      uint16_t* const w_list = reinterpret_cast<uint16_t*>(s_a + kFOffList) + wave * kFListStride;
-      uint16_t* const w_rcell = reinterpret_cast<uint16_t*>(s_a + kFOffRuns) + wave * 64;
-      uint16_t* const w_rbase = w_rcell + 4 * 64;
-      uint16_t* const w_rlen = w_rbase + 4 * 64;
-      const uint32_t mycell = search ? (uint32_t)(((cx - ox0) * Dy + (cy - oy0)) * Dz + (cz - oz0)) : 0xffffffffu;
-      const uint32_t prevcell = __shfl_up(mycell, 1, 64);
-      const bool leader = search && (lane == 0 || mycell != prevcell);
-      const unsigned long long lmask = __ballot(leader);
-      const int nruns = __popcll(lmask);
-      // index of the last leader at or below this lane
-      const int myrun = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(lmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lmask, 0u)) + (leader ? 1 : 0) - 1;
-      if (leader) w_rcell[myrun] = (uint16_t)mycell;
-      const int half = lane >> 5, g = lane & 31;
-      const bool gact = g < kp.num_neighbors;
-      const int goff = gact ? s_goff[g] : 0;
+    // lane g of every wave holds the offset of neighbour cell g: a scalar per cell through v_readlane.  Read by ALL lanes, outside
+    // the divergent search below: v_readlane takes the register of a lane whatever its exec bit, and a lane without a query point
+    // (partial last tile, point outside the key range) would otherwise hand over a register it never wrote
+    const int goff_l = (use_lds && (lane & 31) < 27) ? s_goff[lane & 31] : 0;
+    if (use_lds && search) {
+      // ---- per lane: the 27 (1 / 7 / 19) neighbour cells in the reference's order (ivox3d.h:211-235), nine cell words at a time;
+      //      every occupied cell hands over up to kFBatch candidates per trip, fetched together (their addresses are start, start + 1, ...:
+      //      no pointer chase, no end-of-run test); strict '<' keeps equal distances in visit order.
       const char* const pbase = reinterpret_cast<const char*>(s_pts);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      int runs_done = 0;
-      while (runs_done < nruns) {   // passes: as many runs as the wave's list holds (wave-uniform control flow)
-        const int r_first = runs_done;
-        uint32_t sbase = 0, smax = 0;
-        int r = r_first;
-        for (; r < nruns; r += 2) {
-          // lanes 0..26 resolve the cells of run r, lanes 32..58 those of run r + 1
-          const int rr = r + half;
-          uint32_t start = 0, cnt = 0;
-          if (gact && rr < nruns) {
-            const int c = (int)w_rcell[rr] + goff;
-            const uint32_t h = s_cell[c];
-            if (h != (uint32_t)kFNoCell) { start = h; cnt = s_cnt[c]; }
-          }
-          const uint32_t incl = scan_add_half(cnt);
-          const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31), tot1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-          const bool has1 = r + 1 < nruns;
-          const uint32_t p0 = (tot0 + 3u) & ~3u, p1 = (tot1 + 3u) & ~3u;   // groups of four
-          const bool over0 = p0 > (uint32_t)kFListCap, over1 = has1 && p1 > (uint32_t)kFListCap;
-          const uint32_t need0 = over0 ? 0u : p0, need1 = (has1 && !over1) ? p1 : 0u;
-          if (sbase + need0 > (uint32_t)kFListCap) break;   // run r opens the next pass (a pass always takes its first run: sbase = 0 there)
-          const bool take1 = sbase + need0 + need1 <= (uint32_t)kFListCap;
-          const bool over = half ? over1 : over0;
-          const bool mine = rr < nruns && !over && (half == 0 || take1);
-          const uint32_t rbase = sbase + (half ? need0 : 0u);
-          const uint32_t tot = half ? tot1 : tot0, padded = half ? p1 : p0;
-          if (mine) {
-            const uint32_t pos = rbase + (incl - cnt);
-            for (uint32_t j = 0; j < cnt; j++) w_list[pos + j] = (uint16_t)((start + j) << 4);
-            if ((uint32_t)g < padded - tot) w_list[rbase + tot + (uint32_t)g] = (uint16_t)kFPadOff;
-            if (g == 31) { w_rbase[rr] = (uint16_t)rbase; w_rlen[rr] = (uint16_t)padded; }
-          } else if (rr < nruns && over && g == 31) {
-            w_rlen[rr] = kFOversize;
-          }
-          const uint32_t used1 = take1 ? need1 : 0u;
-          smax = max(smax, max(need0, used1));
-          sbase += need0 + used1;
-          if (has1 && !take1) { r += 1; break; }   // run r + 1 opens the next pass
+      const int cell0 = ((cx - ox0) * Dy + (cy - oy0)) * Dz + (cz - oz0);
+      const int nn = kp.num_neighbors;
+      // One cell per trip, the loop NOT unrolled: the search is ~130 instructions that stay in the instruction cache.  (Unrolled
+      // over the cells -- 27x in the round-2 kernel, 9x in this kernel's first counted form -- the same work ran 7-12x slower per
+      // candidate than a compact loop: profiles/r03_flat_candidate_lists_experiment.txt, r03_search_code_size.txt.)
+      uint32_t e_next = s_cell[cell0 + __builtin_amdgcn_readlane(goff_l, 0)];
+#pragma unroll 1
+      for (int g = 0; g < nn; g++) {
+        const uint32_t e = e_next;
+        if (g + 1 < nn) e_next = s_cell[cell0 + __builtin_amdgcn_readlane(goff_l, g + 1)];   // the next cell's word, in flight under this cell's candidates
+        const uint32_t c = e >> 16;
+        if (c) {
+          const uint32_t o = (e & 0xffffu) << 4;
+          const float4 m0 = lds_point(pbase, o), m1 = lds_point(pbase, o + 16u), m2 = lds_point(pbase, o + 32u), m3 = lds_point(pbase, o + 48u);
+          if (STATS) n_cand += c;
+          best_offer(best, m0, q, o, kp.max_range_sq);
+          if (c > 1u) best_offer(best, m1, q, o + 16u, kp.max_range_sq);
+          if (c > 2u) best_offer(best, m2, q, o + 32u, kp.max_range_sq);
+          if (c > 3u) best_offer(best, m3, q, o + 48u, kp.max_range_sq);
+          keep_w(m0, m1, m2, m3);
+#pragma unroll 1
+          for (uint32_t j = kFBatch; j < c; j++) best_offer(best, lds_point(pbase, o + 16u * j), q, o + 16u * j, kp.max_range_sq);
         }
-        runs_done = r < nruns ? r : nruns;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        PCMF_STAMP(3)   // runs -> candidate lists
-        // ---- flat search of the lanes whose run was listed in this pass ----------------------------
-        uint32_t len = 0, lbase = 0;
-        if (search && myrun >= r_first && myrun < runs_done) {
-          const uint32_t l = w_rlen[myrun];
-          if (l == (uint32_t)kFOversize) oversize = true;
-          else { len = l; lbase = w_rbase[myrun]; }
-        }
-        const char* const lptr = reinterpret_cast<const char*>(w_list + lbase);
-        uint2 ids = make_uint2(0u, 0u);
-        if (len > 0u) ids = *reinterpret_cast<const uint2*>(lptr);
-        for (uint32_t t = 0; t < smax; t += 4u) {
-          if (t < len) {
-            const uint32_t o0 = ids.x & 0xffffu, o1 = ids.x >> 16, o2 = ids.y & 0xffffu, o3 = ids.y >> 16;
-            const float4 m0 = lds_point(pbase, o0), m1 = lds_point(pbase, o1), m2 = lds_point(pbase, o2), m3 = lds_point(pbase, o3);
-            ids = *reinterpret_cast<const uint2*>(lptr + 2u * (t + 4u));   // the next group (behind the last one: within the stride)
-            if (STATS) n_cand += (o0 != kFPadOff) + (o1 != kFPadOff) + (o2 != kFPadOff) + (o3 != kFPadOff);
-            best_offer(best, m0, q, o0, kp.max_range_sq);
-            best_offer(best, m1, q, o1, kp.max_range_sq);
-            best_offer(best, m2, q, o2, kp.max_range_sq);
-            best_offer(best, m3, q, o3, kp.max_range_sq);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // the next pass rewrites the list
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        PCMF_STAMP(4)   // flat search
       }
 #pragma unroll
       for (int j = 0; j < K; j++) best.i[j] >>= 4;
     }
   }
-  // lanes without a list: the whole tile (voxel box or staged points beyond the LDS budget) or a run whose candidates cannot fit one
-  if (search && (!use_lds || oversize)) {
-    best_init(best, kp.max_range_sq);
+  // tile on the global path (voxel box or staged points beyond the LDS budget)
+  if (search && !use_lds) {
     knn_global<STATS>(tg, q, cx, cy, cz, kp.num_neighbors, kp.max_range_sq, best, n_cand, n_probe);
-    if (use_lds) {   // the fit stage reads staged points: the neighbours lie in the staged bricks, translate their map indices back
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        uint32_t si = 0;
-        if (best.d[j] < __builtin_inff()) {
-          int b = 0;
-          while (b + 1 < s_bbox[6] && !(best.i[j] >= s_bps[b] && best.i[j] - s_bps[b] < s_boff[b + 1] - s_boff[b])) b++;
-          si = s_boff[b] + (best.i[j] - s_bps[b]);
-        }
-        best.i[j] = si;
-      }
-    }
   }
   best_finish(best);
+  PCMF_STAMP(4)   // search
   if (!use_lds) {   // tile on the global path: every lane stages its own neighbours, the fit queue below then serves all tiles alike
 #pragma unroll
     for (int j = 0; j < K; j++) {
@@ -413,6 +334,10 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
   {
     const bool job34 = live && best.m >= KMIN && best.m < K;   // the double path (common_lib.h:210-226)
     const unsigned long long b5 = __ballot(job5), b34 = __ballot(job34);
+    if (STATS) {   // plane memo: lanes with five neighbours / lanes that had to fit
+      const unsigned long long bf = __ballot(five);
+      if (lane == 0) { atomicAdd(&stats[5], (unsigned long long)__popcll(bf)); atomicAdd(&stats[6], (unsigned long long)__popcll(b5)); }
+    }
     uint32_t base5 = 0, base34 = 0;
     if (lane == 0) {
       if (b5) base5 = atomicAdd(&s_ctr[0], (uint32_t)__popcll(b5));
@@ -462,52 +387,9 @@ __global__ void __launch_bounds__(256, 4) k_linearize_flat(const PairDesc* __res
     }
   }
 
-  // ---- residual / Jacobian of this lane's point -> one 8-double row in LDS ---------------------------
-  double* const s_row = reinterpret_cast<double*>(s_pts);   // [256][8]: J0..J5, e, selected
-  double* const s_grp = s_row + 256 * 8;                    // [8][32] group partials
-  {
-    float row[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      bool sel = !(pl.x != pl.x);
-      if (sel) {
-        const float pd2 = pl.x * q[0] + pl.y * q[1] + pl.z * q[2] + pl.w;  // laser_mapping.cc:627-629
-        sel = pn_body > 81.f * pd2 * pd2;                                  // :631
-        if (sel) {
-          // left-perturbation Jacobian of e = n.(T p) + d :  [ (q x n)^T , n^T ]
-          row[0] = q[1] * pl.z - q[2] * pl.y;
-          row[1] = q[2] * pl.x - q[0] * pl.z;
-          row[2] = q[0] * pl.y - q[1] * pl.x;
-          row[3] = pl.x; row[4] = pl.y; row[5] = pl.z;
-          row[6] = pd2;
-          row[7] = 1.f;
-        }
-      }
-      if (WRITE_PLANES) gstore4(d.planes + i, sel ? pl : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f));   // the selected set, for trial passes / parity hooks
-    }
-    double2* dst = reinterpret_cast<double2*>(s_row + threadIdx.x * 8);
-#pragma unroll
-    for (int a = 0; a < 4; a++) dst[a] = make_double2((double)row[2 * a], (double)row[2 * a + 1]);
-  }
-  __syncthreads();
-  // ---- 29 sums over the tile's 256 rows: thread (group g, term j) adds 32 rows in double --------------
-  {
-    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double v = 0.0;
-    if (j < kNumSums) {
-      const int ia = c_term_a[j], ib = c_term_b[j];
-      const double* r0 = s_row + (g * 32) * 8;
-#pragma unroll 8
-      for (int k = 0; k < 32; k++) v = fma(r0[k * 8 + ia], r0[k * 8 + ib], v);
-    }
-    s_grp[g * kPartialStride + j] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNumSums) {
-    double v = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8; g++) v += s_grp[g * kPartialStride + threadIdx.x];
-    gstore_d(d.partials + (size_t)tile_x * kPartialStride + threadIdx.x, v);
-  }
+  // ---- residual / Jacobian row of every lane, the 29 sums of the tile (the staged points' LDS is free: see the barrier above) ----
+  static_assert(sizeof(float4) * kFCapPts >= (size_t)kReduceLdsBytes, "the reduction rows alias the staged points");
+  residual_and_reduce<WRITE_PLANES>(d, i, tile_x, live, pl, q, pn_body, s_pts);
   PCMF_STAMP(6)   // memo store + residual + workgroup reduction
   if (TIMING && threadIdx.x == 0) atomicAdd(&stats[15], 1ull);
   if (STATS) {

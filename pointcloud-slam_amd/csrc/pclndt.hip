@@ -496,20 +496,26 @@ __global__ void __launch_bounds__(256) k_pclndt_batch_step(const NdtObject* __re
       }
     }
     __syncthreads();
+    // the Newton direction the step may ask for, by the whole workgroup: H and g of this evaluation (phase LS_HESS: the row holds
+    // H only, g is the machine's).  Phase LS_ITER never reaches a Newton step in the same turn.
+    __shared__ SvdScratch s_svd;
+    __shared__ double s_mg[6], s_delta[6], s_curg[6];
+    __shared__ int s_phase;
     if (threadIdx.x < kNdtStride) {
       double t = 0.0;
       for (int k = 0; k < 16; k++) t += s_grp[k][threadIdx.x];
       s_row[threadIdx.x] = t;
     }
+    // the machine's phase and gradient are read ONCE, before the barrier: thread 0 rewrites both in ndt_machine_advance below, and a
+    // wave that read them from memory after it (phase LS_ITER: no barrier between) would branch into svd_solve6_block's barriers
+    // alone (round-2 advisor finding)
+    if (threadIdx.x == 0) s_phase = ms[o].phase;
+    if (threadIdx.x < 6) s_curg[threadIdx.x] = ms[o].cur.g[threadIdx.x];
     __syncthreads();
-    // the Newton direction the step may ask for, by the whole workgroup: H and g of this evaluation (phase LS_HESS: the row holds
-    // H only, g is the machine's).  Phase LS_ITER never reaches a Newton step in the same turn.
-    __shared__ SvdScratch s_svd;
-    __shared__ double s_mg[6], s_delta[6];
-    const int phase = ms[o].phase;
+    const int phase = s_phase;
     const bool want = phase != ndtomp::NDT_PH_LS_ITER;
     if (want) {
-      if (threadIdx.x < 6) s_mg[threadIdx.x] = -(phase == ndtomp::NDT_PH_LS_HESS ? ms[o].cur.g[threadIdx.x] : s_row[36 + threadIdx.x]);
+      if (threadIdx.x < 6) s_mg[threadIdx.x] = -(phase == ndtomp::NDT_PH_LS_HESS ? s_curg[threadIdx.x] : s_row[36 + threadIdx.x]);
       __syncthreads();
       svd_solve6_block(s_row, s_mg, s_delta, s_svd);
     }

@@ -3,7 +3,8 @@
 // (ndt_omp/include/pclomp/ndt_omp_impl.hpp:69-156, 593-833) around a device "evaluate" callback.
 // Eigen pieces the reference calls and their restatement here:
 //   Matrix3f::eulerAngles(0,1,2), AngleAxis<float>::toRotationMatrix, Translation * AngleAxis products (float),
-//   JacobiSVD<Matrix6d>::solve (one-sided Jacobi; rank threshold diagSize * epsilon * sigma_max).
+//   JacobiSVD<Matrix6d>::solve (two-sided Jacobi with real_2x2_jacobi_svd, Eigen/src/SVD/JacobiSVD.h; rank threshold
+//   diagSize * epsilon * sigma_max).
 #pragma once
 #include "dev_linalg.h"
 

@@ -579,6 +579,15 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   const bool is_lm = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;
   const bool write_sel = is_lm;  // trial passes re-use the planes of the selected set
   const bool legacy_search = (g.flags & PCM_FLAG_LEGACY_SEARCH) != 0;   // the round-2 per-cell search kernel (A/B)
+  const bool ref_order = g.model == PCM_MODEL_P2PLANE && (g.flags & PCM_FLAG_REFERENCE_KNN_ORDER) != 0;   // neighbours in libstdc++'s nth_element order
+  if (ref_order) {
+    for (int i = 0; i < n; i++) {
+      if (ctxs[i]->map.max_voxel_points > (uint32_t)kRefMaxVoxelPoints) {
+        c0->err = "PCM_FLAG_REFERENCE_KNN_ORDER supports at most " + std::to_string(kRefMaxVoxelPoints) + " points per voxel (this map: " + std::to_string(ctxs[i]->map.max_voxel_points) + ")";
+        return PCM_ERR_UNSUPPORTED;
+      }
+    }
+  }
 
   int rounds_done = 0;
   size_t prof_used = 0;
@@ -614,6 +623,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     if (ndt) launch_ndt(st, w->d_descs, w->d_states, kpr, nl, ndt_kind(g.model), false);
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
+    else if (ref_order) launch_linearize_reforder(st, w->d_descs, w->d_states, kpr, nl, write_sel);
     else if (!legacy_search) launch_linearize_flat(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (timed) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
@@ -674,6 +684,8 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     c0->stats.tiles += hs[3];
     c0->stats.tiles_lds_grid += hs[4];
     c0->stats.tiles_lds_points += hs[2];
+    c0->stats.planes_wanted += hs[5];
+    c0->stats.planes_fitted += hs[6];
   }
   if (stats_on) {
     double ms = 0.0, ms2 = 0.0;
@@ -725,6 +737,10 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
   kp1.do_step = 0;   // the last workgroup exports the sums instead of stepping
   if (ndt) launch_ndt(c->stream, w->d_descs, w->d_states, kp1, 1, ndt_kind(c->cfg.model), !linearize);
   else if (is_gicp(c->cfg.model)) launch_gicp(c->stream, w->d_descs, w->d_states, kp1, 1, c->cfg.model == PCM_MODEL_VGICP, !linearize);
+  else if (linearize && (c->cfg.flags & PCM_FLAG_REFERENCE_KNN_ORDER)) {
+    if (c->map.max_voxel_points > (uint32_t)kRefMaxVoxelPoints) { c->err = "PCM_FLAG_REFERENCE_KNN_ORDER supports at most " + std::to_string(kRefMaxVoxelPoints) + " points per voxel"; return PCM_ERR_UNSUPPORTED; }
+    launch_linearize_reforder(c->stream, w->d_descs, w->d_states, kp1, 1, true);
+  }
   else if (linearize && !(c->cfg.flags & PCM_FLAG_LEGACY_SEARCH)) launch_linearize_flat(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);

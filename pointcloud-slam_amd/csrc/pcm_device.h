@@ -39,6 +39,7 @@ struct BrickSlot {
 };
 static_assert(sizeof(BrickSlot) == 32, "BrickSlot must be 32 bytes");
 constexpr uint32_t kMaxBrickSlots = 1u << 22;
+constexpr int kRefMaxVoxelPoints = 121;   // PCM_FLAG_REFERENCE_KNN_ORDER: most points one voxel may hold (the kernel's private candidate array is 27 x 5 + this)
 constexpr uint32_t kMaxTagCount = (1u << 22) - 1u;   // points of a voxel as its head point's tag carries them (bits 9..30 of pts.w)
 
 __host__ __device__ inline uint64_t pack_brick(int bx, int by, int bz) {

@@ -37,6 +37,7 @@ struct TargetMap {   // layout: pcm_device.h
   GaussVoxel* gvox = nullptr;   // NDT models
   uint32_t* order = nullptr;    // input index of every map point (kept on request: GICP covariances are reported in input order)
   uint32_t cap = 0, num_voxels = 0, num_bricks = 0, num_points = 0;
+  uint32_t max_voxel_points = 0;   // most points in one voxel
   float res = 0.f, inv_res = 0.f;
   int coord_mode = 0;
   bool valid = false;
@@ -50,7 +51,7 @@ struct TargetMap {   // layout: pcm_device.h
     if (order) hipFree(order);
     gvox = nullptr; order = nullptr;
     bricks = nullptr; bmask = nullptr; bpref = nullptr; vox_start = nullptr; pts = nullptr;
-    cap = num_voxels = num_bricks = num_points = 0; valid = false;
+    cap = num_voxels = num_bricks = num_points = 0; max_voxel_points = 0; valid = false;
   }
 };
 
@@ -106,6 +107,7 @@ void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairSta
                       unsigned long long* d_stats, bool timing);
 void launch_linearize_flat(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                            unsigned long long* d_stats, bool timing = false);
+void launch_linearize_reforder(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);
 void launch_linearize_fused(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, unsigned char* d_flags_row);
 void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp);
 void launch_lio_finish(hipStream_t stream, const double* d_partials, int nblocks, double* d_out);

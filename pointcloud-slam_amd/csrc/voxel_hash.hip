@@ -136,6 +136,15 @@ __global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* _
   out[i] = p;
 }
 
+// most points in one voxel (PCM_FLAG_REFERENCE_KNN_ORDER sizes a private array by it)
+__global__ void k_max_voxel_points(const uint32_t* __restrict__ vox_start, uint32_t nvox, unsigned int* __restrict__ out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int c = v < nvox ? vox_start[v + 1] - vox_start[v] : 0u;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) c = max(c, (unsigned int)__shfl_xor((int)c, off, 64));
+  if ((threadIdx.x & 63) == 0 && c) atomicMax(out, c);
+}
+
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 // scratch arrays come from the device's stream-ordered memory pool (hipMallocAsync): after the first frames an allocation
 // is a pool hit, no driver call and no implicit device synchronisation -- the sliding map rebuilds every frame
@@ -238,7 +247,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   if (n == 0) { *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
   uint64_t *keys = nullptr, *keys_s = nullptr;
   uint32_t *idx = nullptr, *idx_s = nullptr, *vflag = nullptr, *vrank = nullptr;
-  int* d_flags = nullptr;  // [0] out-of-range flag, [1] brick count
+  int* d_flags = nullptr;  // [0] out-of-range flag, [1] brick count, [2] most points in one voxel
   void *tmp = nullptr, *tmp2 = nullptr;
   size_t tmp_bytes = 0, tmp2_bytes = 0;
   int rc = PCM_OK;
@@ -255,8 +264,8 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   CK(hipMallocAsync(&idx_s, sizeof(uint32_t) * n, stream));
   CK(hipMallocAsync(&vflag, sizeof(uint32_t) * n, stream));
   CK(hipMallocAsync(&vrank, sizeof(uint32_t) * n, stream));
-  CK(hipMallocAsync(&d_flags, 2 * sizeof(int), stream));
-  CK(hipMemsetAsync(d_flags, 0, 2 * sizeof(int), stream));
+  CK(hipMallocAsync(&d_flags, 3 * sizeof(int), stream));
+  CK(hipMemsetAsync(d_flags, 0, 3 * sizeof(int), stream));
   k_point_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, res, inv_res, coord_mode, keys, idx, d_flags);
   CK(hipGetLastError());
   CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
@@ -344,6 +353,9 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     CK(hipGetLastError());
     k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, keys_s, vrank, map->vox_start, n, map->pts);
     CK(hipGetLastError());
+    k_max_voxel_points<<<cdiv(nvox, 256), 256, 0, stream>>>(map->vox_start, nvox, reinterpret_cast<unsigned int*>(d_flags + 2));
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(&map->max_voxel_points, d_flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));   // complete at the synchronize below
     if (want_gauss) {
       CK(hipMalloc(&map->gvox, sizeof(GaussVoxel) * ((size_t)nvox + 1)));
       k_gauss_voxels<<<cdiv(nvox, 128), 128, 0, stream>>>(map->pts, map->vox_start, nvox, map->gvox);

@@ -23,7 +23,7 @@ def pair_ids_for_rank(pairs_per_rank: int, rank: int) -> list:
     return [rank * pairs_per_rank + i for i in range(pairs_per_rank)]
 
 
-def run_pipelined_steps(k: int, n_slots: int, sub_step, gather=None, stagger_s: float = 0.0, on_thread_start=None):
+def run_pipelined_steps(k: int, n_slots: int, sub_step, gather=None, stagger_s: float = 0.0, on_thread_start=None, on_error=None):
     """k passes over every pipeline slot of this rank; returns the last result of every slot.
 
     ``sub_step(j, wait_prev)`` runs one pass of slot j on the caller's stream of that slot and returns when the slot's result
@@ -66,11 +66,15 @@ def run_pipelined_steps(k: int, n_slots: int, sub_step, gather=None, stagger_s: 
                 for j in range(n_slots):
                     done[step][j].wait()
                     if errs:
+                        if on_error:
+                            on_error(errs[0])   # see run_rotating_steps: the peers are inside this collective
                         return
                     gather(j)
                     gathered[step][j].set()
         except Exception as e:
             errs.append(e)
+            if on_error:
+                on_error(e)
         finally:
             for row in gathered:
                 for ev in row:
@@ -90,7 +94,7 @@ def run_pipelined_steps(k: int, n_slots: int, sub_step, gather=None, stagger_s: 
     return last
 
 
-def run_rotating_steps(k: int, n_slots: int, step_fn, gather=None, stagger_s: float = 0.0, on_thread_start=None):
+def run_rotating_steps(k: int, n_slots: int, step_fn, gather=None, stagger_s: float = 0.0, on_thread_start=None, on_error=None):
     """k passes over the rank's WHOLE batch, pass s on pipeline slot ``s % n_slots``; returns the result of the last pass.
 
     ``step_fn(slot, wait_prev)`` runs one pass on the slot's own registration objects / stream and returns when the slot's result
@@ -100,6 +104,11 @@ def run_rotating_steps(k: int, n_slots: int, step_fn, gather=None, stagger_s: fl
     Unlike :func:`run_pipelined_steps` (a fixed subset of the pairs per slot) every slot sees the same mix of fast and slow
     converging pairs, so no slot is the permanent critical path; the slow tail of pass s runs under the bulk of pass s + 1.
     Collectives: ONE thread issues them in pass order -- identical on every rank by construction, on ONE communicator.
+
+    A local failure (an exception in ``step_fn`` or ``gather``) leaves this rank's remaining collectives unissued while every other
+    rank is inside its all-gather: ``on_error(exc)`` is called once, from the thread that saw it, BEFORE the error is raised in
+    the caller -- a multi-rank job passes a function that ends the process (or aborts the process group), so the peers fail
+    fast on a closed connection instead of hanging until the backend's timeout (round-2 advisor finding).
     """
     import threading
     import time
@@ -135,11 +144,15 @@ def run_rotating_steps(k: int, n_slots: int, step_fn, gather=None, stagger_s: fl
             for s in range(k):
                 done[s].wait()
                 if errs:
+                    if on_error:
+                        on_error(errs[0])
                     return
                 gather(s % n_slots)
                 gathered[s].set()
         except Exception as e:
             errs.append(e)
+            if on_error:
+                on_error(e)
         finally:
             for ev in gathered:
                 ev.set()

@@ -66,3 +66,13 @@ def test_adapter_header_compiles_against_stub_pcl_and_links_against_the_c_abi():
         subprocess.run(["g++", "-std=c++17", "-x", "c++", "-", "-o", "/tmp/pcm_adapter_link_check"] + inc +
                        ["-L", os.path.dirname(lib), "-lpcm_amd", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--unresolved-symbols=ignore-in-shared-libs"],
                        input=SRC.encode(), check=True)
+
+
+def test_rccl_gather_example_compiles():
+    """examples/gather_poses_rccl.cpp (the C++ caller's pcm_align_batch(device_out) -> ncclAllGather) against
+    the image's RCCL and HIP headers."""
+    import pytest
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no RCCL headers")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "examples", "gather_poses_rccl.cpp")], check=True)

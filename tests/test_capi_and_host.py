@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(pcm):
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.pcm_abi_version() == 2
+    assert L.pcm_abi_version() == 3
 
 
 def test_struct_layouts_match_header(pcm):

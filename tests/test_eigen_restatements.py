@@ -4,16 +4,40 @@
 Each function follows an Eigen source file that is in the reference tree (cited in the header); here every one of
 them is compared with float64 numpy.linalg on >= 10 000 seeded random cases, with the error bound written in the
 test, so that a misreading shared by the oracle and the device code (which restates the same algorithms a second
-time in csrc/) cannot pass.  Parity with the reference itself stays "unpinned by fixtures": the reference holds no
+time in csrc/) cannot pass.  Every check runs on BOTH restatements: the oracle's and -- compiled for the host through
+tests/dev_linalg_hooks.cpp -- the device twins the kernels run.  Parity with the reference itself stays "unpinned by fixtures": the reference holds no
 golden vector for these pieces."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
+import os
+import subprocess
+
 from oracle.loader import lib
 
 N = 20000
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_DEV = None
+
+
+def _device_twins():
+    """The DEVICE twins (csrc/dev_linalg.h, lsq_step.h, plane_fit.h) compiled for the host behind the same hook names
+    (tests/dev_linalg_hooks.cpp), -ffp-contract=off like the kernels."""
+    global _DEV
+    if _DEV is None:
+        so = "/tmp/pcm_dev_linalg_hooks.so"
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I", os.path.join(ROOT, "pointcloud-slam_amd", "csrc"),
+                        os.path.join(ROOT, "tests", "dev_linalg_hooks.cpp"), "-o", so], check=True)
+        _DEV = C.CDLL(so)
+    return _DEV
+
+
+@pytest.fixture(params=["oracle", "device_twin"])
+def L(request):
+    """Every check below runs twice: on oracle/orc_eigen.h and on the code the kernels run."""
+    return lib() if request.param == "oracle" else _device_twins()
 EPS64 = np.finfo(np.float64).eps
 EPS32 = np.finfo(np.float32).eps
 
@@ -30,14 +54,14 @@ def _spd(rng, n, dim, cond_max=1e6):
     return 0.5 * (A + np.swapaxes(A, 1, 2)), ev
 
 
-def test_ldlt6_solve_matches_numpy():
+def test_ldlt6_solve_matches_numpy(L):
     """LDLT<Matrix6d>::solve: relative residual and error vs numpy.linalg.solve bounded by cond * 64 eps on SPD systems
     (normal equations H + lambda I are SPD), and an indefinite / singular batch through the pseudo-inverse rule."""
     rng = np.random.default_rng(1)
     A, ev = _spd(rng, N, 6)
     b = rng.standard_normal((N, 6))
     x = np.zeros((N, 6))
-    lib().orc_test_eig_ldlt6(C.c_long(N), _p(A), _p(b), _p(x))
+    L.orc_test_eig_ldlt6(C.c_long(N), _p(A), _p(b), _p(x))
     ref = np.linalg.solve(A, b[..., None])[..., 0]
     cond = ev.max(1) / ev.min(1)
     err = np.linalg.norm(x - ref, axis=1) / np.linalg.norm(ref, axis=1)
@@ -47,21 +71,21 @@ def test_ldlt6_solve_matches_numpy():
     iu = np.triu_indices(6, 1)
     A2[:, iu[0], iu[1]] = 1e300
     x2 = np.zeros((N, 6))
-    lib().orc_test_eig_ldlt6(C.c_long(N), _p(A2), _p(b), _p(x2))
+    L.orc_test_eig_ldlt6(C.c_long(N), _p(A2), _p(b), _p(x2))
     assert np.array_equal(x, x2)
     # rank-deficient PSD systems: a zero pivot gives a zero component (pseudo-inverse of D, LDLT.h:593-600), no NaN / inf
     B = rng.standard_normal((1000, 6, 3))
     S = B @ np.swapaxes(B, 1, 2)
     bb = (S @ rng.standard_normal((1000, 6, 1)))[..., 0]     # consistent right-hand sides
     xs = np.zeros((1000, 6))
-    lib().orc_test_eig_ldlt6(C.c_long(1000), _p(np.ascontiguousarray(S)), _p(bb), _p(xs))
+    L.orc_test_eig_ldlt6(C.c_long(1000), _p(np.ascontiguousarray(S)), _p(bb), _p(xs))
     assert np.all(np.isfinite(xs))
     res = np.linalg.norm((S @ xs[..., None])[..., 0] - bb, axis=1) / np.linalg.norm(bb, axis=1)
     assert np.median(res) < 1e-6
 
 
 @pytest.mark.parametrize("rows", [5, 4, 3])
-def test_colpivqr_solve_matches_numpy_lstsq(rows):
+def test_colpivqr_solve_matches_numpy_lstsq(L, rows):
     """ColPivHouseholderQR(A).solve(b) for the plane fit's rows x 3 systems = the least-squares solution: double vs
     numpy.linalg.lstsq to cond * 256 eps; the float instantiation (rows = 5) against the float64 answer of the same
     float inputs to cond * 64 eps32."""
@@ -69,7 +93,7 @@ def test_colpivqr_solve_matches_numpy_lstsq(rows):
     A = rng.standard_normal((N, rows, 3)) * np.exp(rng.uniform(-2, 2, (N, 1, 3))) + rng.uniform(-20, 20, (N, 1, 3))
     b = -np.ones((N, rows))
     x = np.zeros((N, 3))
-    lib().orc_test_eig_colpivqr_d(C.c_long(N), C.c_int(rows), _p(np.ascontiguousarray(A)), _p(b), _p(x))
+    L.orc_test_eig_colpivqr_d(C.c_long(N), C.c_int(rows), _p(np.ascontiguousarray(A)), _p(b), _p(x))
     sv = np.linalg.svd(A, compute_uv=False)
     cond = sv[:, 0] / sv[:, -1]
     ref = np.stack([np.linalg.lstsq(A[i], b[i], rcond=None)[0] for i in range(2000)])
@@ -84,7 +108,7 @@ def test_colpivqr_solve_matches_numpy_lstsq(rows):
         Af = A.astype(np.float32)
         bf = b.astype(np.float32)
         xf = np.zeros((N, 3), np.float32)
-        lib().orc_test_eig_colpivqr_f(C.c_long(N), C.c_int(rows), _p(np.ascontiguousarray(Af)), _p(bf), _p(xf))
+        L.orc_test_eig_colpivqr_f(C.c_long(N), C.c_int(rows), _p(np.ascontiguousarray(Af)), _p(bf), _p(xf))
         A64 = Af.astype(np.float64)
         ref = np.stack([np.linalg.lstsq(A64[i], b[i], rcond=None)[0] for i in range(2000)])
         sv = np.linalg.svd(A64[:2000], compute_uv=False)
@@ -94,7 +118,7 @@ def test_colpivqr_solve_matches_numpy_lstsq(rows):
         assert np.all(err[ok] < 64 * EPS32 * cond[ok] ** 2), float((err[ok] / (EPS32 * cond[ok] ** 2)).max())
 
 
-def test_colpivqr_zero_column_is_dropped():
+def test_colpivqr_zero_column_is_dropped(L):
     """Eigen counts pivots that are nonzero "in the exact sense" (threshold_helper, ColPivHouseholderQR.h:510,525-526):
     a column of zeros is dropped -- its component of x is exactly 0 -- and the rest solves the remaining least-squares
     problem; a merely ill-conditioned matrix is NOT truncated (the plane test of esti_plane rejects those fits)."""
@@ -105,7 +129,7 @@ def test_colpivqr_zero_column_is_dropped():
     A[np.arange(n), :, zc] = 0.0
     b = -np.ones((n, 5))
     x = np.zeros((n, 3))
-    lib().orc_test_eig_colpivqr_d(C.c_long(n), C.c_int(5), _p(np.ascontiguousarray(A)), _p(b), _p(x))
+    L.orc_test_eig_colpivqr_d(C.c_long(n), C.c_int(5), _p(np.ascontiguousarray(A)), _p(b), _p(x))
     assert np.all(np.isfinite(x))
     assert np.all(x[np.arange(n), zc] == 0.0)
     ref = np.stack([np.linalg.lstsq(A[i], b[i], rcond=None)[0] for i in range(n)])
@@ -113,7 +137,7 @@ def test_colpivqr_zero_column_is_dropped():
 
 
 @pytest.mark.parametrize("dim", [3, 6])
-def test_jacobi_svd_matches_numpy(dim):
+def test_jacobi_svd_matches_numpy(L, dim):
     """JacobiSVD (two-sided Jacobi): singular values vs numpy to 16 eps * sigma_max, U and V orthogonal to 32 eps,
     U S V^T reconstructs A to 32 eps * sigma_max, values descending; general (non-symmetric) and PSD inputs."""
     rng = np.random.default_rng(10 + dim)
@@ -121,7 +145,7 @@ def test_jacobi_svd_matches_numpy(dim):
     P, _ = _spd(rng, N // 2, dim, 1e8)
     A[: N // 2] = P
     U = np.zeros_like(A); V = np.zeros_like(A); S = np.zeros((N, dim))
-    lib().orc_test_eig_jacobi_svd(C.c_long(N), C.c_int(dim), _p(np.ascontiguousarray(A)), _p(U), _p(S), _p(V))
+    L.orc_test_eig_jacobi_svd(C.c_long(N), C.c_int(dim), _p(np.ascontiguousarray(A)), _p(U), _p(S), _p(V))
     ref = np.linalg.svd(A, compute_uv=False)
     smax = ref[:, :1]
     assert np.all(np.abs(S - ref) < 16 * dim * EPS64 * smax)
@@ -133,7 +157,7 @@ def test_jacobi_svd_matches_numpy(dim):
     assert np.all(np.abs(rec - A).max(axis=(1, 2)) < 32 * dim * EPS64 * smax[:, 0])
 
 
-def test_svd_solve6_matches_numpy():
+def test_svd_solve6_matches_numpy(L):
     """JacobiSVD<Matrix6d>::solve (the Newton step of pclomp NDT): vs numpy.linalg.solve on well-conditioned Hessians
     (cond * 64 eps), and the minimum-norm solution (numpy.linalg.pinv with Eigen's threshold 6 eps sigma_max) on rank-5 ones."""
     rng = np.random.default_rng(21)
@@ -141,7 +165,7 @@ def test_svd_solve6_matches_numpy():
     A[::2] *= -1.0     # NDT Hessians of the score are negative definite near the optimum
     b = rng.standard_normal((N, 6))
     x = np.zeros((N, 6))
-    lib().orc_test_eig_svd_solve6(C.c_long(N), _p(A), _p(b), _p(x))
+    L.orc_test_eig_svd_solve6(C.c_long(N), _p(A), _p(b), _p(x))
     ref = np.linalg.solve(A, b[..., None])[..., 0]
     cond = ev.max(1) / ev.min(1)
     err = np.linalg.norm(x - ref, axis=1) / np.linalg.norm(ref, axis=1)
@@ -150,20 +174,20 @@ def test_svd_solve6_matches_numpy():
     S5 = np.ascontiguousarray(B @ np.swapaxes(B, 1, 2))
     bb = rng.standard_normal((2000, 6))
     xs = np.zeros((2000, 6))
-    lib().orc_test_eig_svd_solve6(C.c_long(2000), _p(S5), _p(bb), _p(xs))
+    L.orc_test_eig_svd_solve6(C.c_long(2000), _p(S5), _p(bb), _p(xs))
     ref = np.stack([np.linalg.pinv(S5[i], rcond=6 * EPS64) @ bb[i] for i in range(2000)])
     err = np.linalg.norm(xs - ref, axis=1) / np.linalg.norm(ref, axis=1)
     assert np.median(err) < 1e-9 and np.quantile(err, 0.99) < 1e-5
 
 
-def test_selfadjoint3_compute_matches_numpy_eigh():
+def test_selfadjoint3_compute_matches_numpy_eigh(L):
     """SelfAdjointEigenSolver<Matrix3d>::compute (tridiagonalisation + implicit QR): eigenvalues ascending, vs
     numpy.linalg.eigh to 16 eps * |lambda|_max; A V = V diag(w) to 32 eps; V orthogonal; only the lower triangle is read."""
     rng = np.random.default_rng(31)
     A, _ = _spd(rng, N, 3, 1e8)
     A[: N // 4] -= np.eye(3) * rng.uniform(0, 5, (N // 4, 1, 1))     # indefinite ones too
     w = np.zeros((N, 3)); V = np.zeros((N, 3, 3)); ok = np.zeros(N, np.int32)
-    lib().orc_test_eig_selfadjoint3(C.c_long(N), _p(A), _p(w), _p(V), _p(ok))
+    L.orc_test_eig_selfadjoint3(C.c_long(N), _p(A), _p(w), _p(V), _p(ok))
     assert ok.all()
     ref = np.linalg.eigvalsh(A)
     amax = np.abs(ref).max(1, keepdims=True)
@@ -173,11 +197,11 @@ def test_selfadjoint3_compute_matches_numpy_eigh():
     assert np.all(np.abs(A @ V - V * w[:, None, :]).max(axis=(1, 2)) < 64 * EPS64 * amax[:, 0])
     A2 = A.copy(); A2[:, 0, 1] = A2[:, 0, 2] = A2[:, 1, 2] = 7e77
     w2 = np.zeros((N, 3)); V2 = np.zeros((N, 3, 3))
-    lib().orc_test_eig_selfadjoint3(C.c_long(N), _p(A2), _p(w2), _p(V2), _p(ok))
+    L.orc_test_eig_selfadjoint3(C.c_long(N), _p(A2), _p(w2), _p(V2), _p(ok))
     assert np.array_equal(w, w2) and np.array_equal(V, V2)
 
 
-def test_selfadjoint3_direct_float_matches_numpy_eigh():
+def test_selfadjoint3_direct_float_matches_numpy_eigh(L):
     """computeDirect (closed form, float; the reference's CUDA kernels): eigenvalues vs float64 eigh of the same float
     matrix.  Eigen documents the closed form as less accurate than the iterative solver: the trigonometric root formula
     loses half the digits where two eigenvalues nearly coincide, so the bound is median < 2 eps32, 99 % < 256 eps32 and
@@ -187,7 +211,7 @@ def test_selfadjoint3_direct_float_matches_numpy_eigh():
     A, _ = _spd(rng, N, 3, 1e3)
     Af = np.ascontiguousarray(A.astype(np.float32))
     w = np.zeros((N, 3), np.float32); V = np.zeros((N, 3, 3), np.float32)
-    lib().orc_test_eig_direct3f(C.c_long(N), _p(Af), _p(w), _p(V))
+    L.orc_test_eig_direct3f(C.c_long(N), _p(Af), _p(w), _p(V))
     ref = np.linalg.eigvalsh(Af.astype(np.float64))
     amax = np.abs(ref).max(1, keepdims=True)
     e = (np.abs(w - ref) / amax).max(1)
@@ -200,18 +224,18 @@ def test_selfadjoint3_direct_float_matches_numpy_eigh():
     assert np.all(np.abs(R[sep]).max(axis=(1, 2)) < 2e3 * EPS32 * amax[sep, 0])
 
 
-def test_inverses_match_numpy():
+def test_inverses_match_numpy(L):
     """Matrix3d / Matrix3f / Matrix4d inverse (cofactors; the Packet2d 4x4 form): |A A^-1 - I| has median < 4 eps cond and maximum < 4 eps cond^2 (8 for the 4x4 form): cofactor inverses are not backward stable, so the worst case carries the condition number twice."""
     rng = np.random.default_rng(51)
     A3, ev = _spd(rng, N, 3, 1e6)
     A3 += 0.1 * rng.standard_normal((N, 3, 3)) * ev.min(1)[:, None, None]     # not exactly symmetric
     R3 = np.zeros_like(A3)
-    lib().orc_test_eig_inv3d(C.c_long(N), _p(np.ascontiguousarray(A3)), _p(R3))
+    L.orc_test_eig_inv3d(C.c_long(N), _p(np.ascontiguousarray(A3)), _p(R3))
     cond = np.linalg.cond(A3)
     r3 = np.abs(A3 @ R3 - np.eye(3)).max(axis=(1, 2)) / (EPS64 * cond)
     assert np.median(r3) < 4 and (r3 / cond).max() < 4, (np.median(r3), (r3 / cond).max())
     A3f = np.ascontiguousarray(A3.astype(np.float32)); R3f = np.zeros_like(A3f)
-    lib().orc_test_eig_inv3f(C.c_long(N), _p(A3f), _p(R3f))
+    L.orc_test_eig_inv3f(C.c_long(N), _p(A3f), _p(R3f))
     okc = cond < 1e4
     r3f = np.abs(A3f.astype(np.float64) @ R3f - np.eye(3)).max(axis=(1, 2))[okc] / (EPS32 * cond[okc])
     assert np.median(r3f) < 4 and (r3f / cond[okc]).max() < 4, (np.median(r3f), (r3f / cond[okc]).max())
@@ -219,7 +243,7 @@ def test_inverses_match_numpy():
     A4 = np.zeros((N, 4, 4)); A4[:, :3, :3] = A3; A4[:, 3, 3] = 1.0
     A4[N // 2:] = rng.standard_normal((N - N // 2, 4, 4))
     R4 = np.zeros_like(A4)
-    lib().orc_test_eig_inv4d(C.c_long(N), _p(A4), _p(R4))
+    L.orc_test_eig_inv4d(C.c_long(N), _p(A4), _p(R4))
     cond4 = np.linalg.cond(A4)
     r4 = np.abs(A4 @ R4 - np.eye(4)).max(axis=(1, 2)) / (EPS64 * cond4)
     assert np.median(r4) < 8 and (r4 / cond4).max() < 8, (np.median(r4), (r4 / cond4).max())

@@ -260,3 +260,63 @@ def test_slot_schedulers_without_a_process_group():
     gathered = []
     with pytest.raises(ValueError):                   # with a gather thread: it must be released, not left waiting for the dead slot
         sh.run_rotating_steps(6, 2, bad, gather=lambda j: gathered.append(j))
+
+
+def _failing_worker(rank, world, port, q):
+    """One rank's step function raises in pass 2: with on_error ending that process the peer must come back (with an error on its
+    closed connection), not hang in the all-gather."""
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    import pointcloud_slam_amd as pcm
+    sh = pcm.sharding
+    blocks = [torch.zeros(4 * sh.RECORD_BYTES, dtype=torch.uint8) for _ in range(2)]
+    calls = {"n": 0}
+
+    def step_fn(slot, wait_prev):
+        calls["n"] += 1
+        if rank == 1 and calls["n"] == 3:
+            raise RuntimeError("injected failure on rank 1")
+        time.sleep(0.01)
+        if wait_prev:
+            wait_prev()
+        return [slot]
+
+    def gather(slot):
+        sh.gather_records(blocks[slot], world)
+
+    def fail_fast(exc):
+        q.put((rank, "on_error: %s" % exc))
+        time.sleep(0.2)   # let the queue feeder thread flush
+        os._exit(13)
+
+    try:
+        sh.run_rotating_steps(8, 2, step_fn, gather, 0.0, on_error=fail_fast)
+        q.put((rank, "finished"))
+    except Exception as e:   # the surviving rank: its collective fails when the peer is gone
+        q.put((rank, "raised: %s" % type(e).__name__))
+
+
+def test_a_failing_rank_does_not_hang_its_peers_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=90)
+    alive = [p.is_alive() for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert not any(alive), "a rank hung after its peer failed"
+    got = {}
+    while not q.empty():
+        r, msg = q.get()
+        got[r] = msg
+    assert got.get(1, "").startswith("on_error"), got
+    assert procs[1].exitcode == 13
+    assert 0 not in got or not got[0].startswith("finished"), got   # rank 0 cannot have completed 8 gathers without its peer

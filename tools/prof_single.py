@@ -36,6 +36,10 @@ for s in range(a.steps):
 dt = (time.perf_counter() - t0) / max(1, a.steps)
 print("linearize passes", [r.num_linearize for r in res], "sum", sum(r.num_linearize for r in res))
 print("ms per batched align (one stream, scans already ordered): %.3f  -> %.0f reg/s" % (dt * 1e3, len(regs) / dt))
+regs[0].reset_stats(); regs[0].set_profiling(2)
+res = pcm.align_batch(regs, g)
+st = regs[0].stats(); regs[0].set_profiling(0)
+print('candidates/point %.2f  tiles staged %.3f  planes wanted %d fitted %d (memo answered %.1f %%)' % (st['candidates'] / max(1, st['point_passes']), st['tiles_lds_points'] / max(1, st['tiles']), st['planes_wanted'], st['planes_fitted'], 100.0 * (1 - st['planes_fitted'] / max(1, st['planes_wanted']))))
 if a.phases:
     regs[0].set_profiling(4)
     res = pcm.align_batch(regs, g)
