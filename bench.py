@@ -370,7 +370,7 @@ def main():
     value = total_regs / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # ---- roofline of the dominant kernel (k_linearize_flat) ------------------------------------------------------------
+    # ---- roofline of the dominant kernel (k_linearize) ------------------------------------------------------------
     # The kernel is a gather + reduction served from LDS: its physical HBM traffic is a few percent of the peak, and the
     # SURVEY §8(d) byte model ("no reuse assumed": query + 27 slots + K-bar candidates per point pass) prices bytes the LDS staging
     # never moves -- round 2's fraction against it exceeded 1.  What bounds it is vector-instruction issue: the roofline is
@@ -390,7 +390,7 @@ def main():
     traffic_p, traffic_ok = load_profile("pmc_traffic.json", workload_key)
     valu_per_wave = float(valu["valu_per_wave"]) if valu else None
     b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
-    roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GIPS, "kernel": "k_linearize_flat",
+    roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GIPS, "kernel": "k_linearize_counted" if (args.flags & 8) else "k_linearize",
             "achieved": None, "frac": None, "traffic": None}
     if valu_per_wave:
         ach = valu_per_wave * waves_per_step / (ms_per_step * 1e-3) / 1e9
@@ -425,7 +425,7 @@ def main():
                                    " (configs[2] = the same pairs at 32 per GPU over 8 GPUs: --gpus 8 --pairs-per-gpu 32)"
                                    % (args.scan_points, args.map_points, args.optimizer, n_local),
                        "pairs_per_gpu": n_local, "batches_in_flight": S, "schedule": args.schedule, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
-                       "flags": args.flags, "plane_memo_within_one_align": not (args.flags & 16), "search_kernel": "legacy per-cell" if (args.flags & 8) else "flat lists",
+                       "flags": args.flags, "search_kernel": "k_linearize_counted" if (args.flags & 8) else "k_linearize",
                        "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},

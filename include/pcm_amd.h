@@ -96,7 +96,7 @@ typedef struct pcm_config {
   int32_t k_correspondences;     /* 20  impl/fast_gicp_impl.hpp:16 */
   int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
   int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
-  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 and 3-4 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics, bit 5 the neighbour row order */
+  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 and 3 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics, bit 5 the neighbour row order */
   int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
   float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
@@ -105,7 +105,14 @@ typedef struct pcm_config {
   float neighbor_search_radius;  /* NDT_P2D / NDT_D2D / VGICP_CUDA: > 0 selects NeighborSearchMethod::DIRECT_RADIUS -- every voxel offset with
                                   * |offset| <= radius + 1e-3, radius in voxels (cuda/ndt_cuda.cu:70-83, cuda/fast_vgicp_cuda.cu:77-90;
                                   * setNeighborSearchMethod(method, radius)); num_neighbors is not read then.  0 (default): off */
+  int32_t covariance_method;     /* VGICP_CUDA: PCM_COV_KNN (k nearest neighbours, default) or PCM_COV_RBF_KERNEL -- NearestNeighborMethod::GPU_RBF_KERNEL
+                                  * of FastVGICPCuda (fast_vgicp_cuda_impl.hpp:107,136; cuda/covariance_estimation_rbf.cu:59-151) */
+  float rbf_kernel_width;        /* 0.25: the weight of a point at squared distance d2 is expf(-rbf_kernel_width * d2)  (fast_vgicp_cuda.cu:25, :81) */
+  float rbf_max_dist;            /* 3.0: points farther than this do not take part  (fast_vgicp_cuda.cu:26; setKernelWidth: 5 x width when not given) */
 } pcm_config;
+
+#define PCM_COV_KNN 0
+#define PCM_COV_RBF_KERNEL 1
 
 #define PCM_FLAG_NO_LDS_STAGING 1   /* probe the global table per lane instead of the per-tile LDS grid */
 #define PCM_FLAG_LIO_REFERENCE_SEMANTICS 4
@@ -114,12 +121,9 @@ typedef struct pcm_config {
  * `p_body.norm() > 81 pd2^2` test keeps its flag and contributes the residual an earlier call -- possibly of an older frame --
  * stored for its index; a point never stored contributes 0).  Set it before pcm_set_source of the first scan.  Off (default):
  * such a point is dropped for that call, the result depends on the current scan, map and state only. */
-#define PCM_FLAG_LEGACY_SEARCH 8     /* P2PLANE: the round-2 search kernel (27 cells walked one after the other, one plane fit per lane) instead of
-                                     * k_linearize_flat; same neighbour lists, planes and sums -- A/B switch, never changes a result */
-#define PCM_FLAG_NO_PLANE_MEMO 16   /* k_linearize_flat: fit every plane in every linearize pass.  Default (off): inside ONE align a point whose five
-                                     * neighbours are those of the previous pass, in the same order, re-uses that pass's plane -- esti_plane
-                                     * (common_lib.h:186-243) sees the ordered neighbour tuple only, so the plane is the same bits; the memo is
-                                     * never read in the first pass of an align and never survives one */
+#define PCM_FLAG_COUNTED_SEARCH 8    /* P2PLANE: k_linearize_counted (linearize_counted.hip: voxel point counts in the LDS cell grid, four candidates per cell and
+                                     * trip, rolled cell loop, DPP reductions) instead of k_linearize; same neighbour lists, planes and sums bit for bit.
+                                     * 14 % fewer vector instructions and a third of the code, measured 12 % SLOWER (profiles/r03_bench_ab_*.json): A/B switch */
 #define PCM_FLAG_REFERENCE_KNN_ORDER 32
 /* P2PLANE align / linearize: hand esti_plane its neighbours in the row order the reference's IVox::GetClosestPoint leaves -- the
  * order of libstdc++'s std::nth_element (jueying_lio/include/ivox3d/ivox3d.h:173-178, ivox3d_node.hpp:176-181) -- instead of
@@ -161,8 +165,6 @@ typedef struct pcm_stats {
   uint64_t timed_launches;       /* launches bracketed by HIP events (= linearize_launches unless profiling bit3 samples them) */
   uint64_t timed_pair_slots;     /* sum of the pair-list lengths of the timed launches ... */
   uint64_t launched_pair_slots;  /* ... and of all launches: the share of point_passes that falls to the timed ones */
-  uint64_t planes_wanted;        /* point passes with exactly five neighbours, i.e. a float plane fit is due (counter passes only) */
-  uint64_t planes_fitted;        /* ... of which the plane memo did not answer: fits actually run */
 } pcm_stats;
 
 typedef struct pcm_ctx pcm_ctx;

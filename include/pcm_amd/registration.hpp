@@ -242,22 +242,14 @@ public:
   }
   void setCorrespondenceRandomness(int) {}                                                       // a no-op there too (fast_vgicp_cuda_impl.hpp:37-38)
   // setNearestNeighborSearchMethod (fast_vgicp_cuda_impl.hpp:64-66): CPU_PARALLEL_KDTREE and GPU_BRUTEFORCE both give the exact
-  // k nearest neighbours the covariances are built from -- one device implementation serves both; the RBF-kernel covariances
-  // (covariance_estimation_rbf.cu) are a different estimator and are not built: selecting them is an error at align() time
+  // k nearest neighbours the covariances are built from -- one device implementation serves both; GPU_RBF_KERNEL selects the
+  // RBF-kernel covariance estimator (cuda/covariance_estimation_rbf.cu:59-151 -> pcm_config.covariance_method = PCM_COV_RBF_KERNEL)
   enum class NearestNeighborMethod { CPU_PARALLEL_KDTREE, GPU_BRUTEFORCE, GPU_RBF_KERNEL };      // fast_vgicp_cuda.hpp:21
-  void setNearestNeighborSearchMethod(NearestNeighborMethod m) { rbf_selected_ = m == NearestNeighborMethod::GPU_RBF_KERNEL; }
-  void setKernelWidth(double kernel_width, double max_dist = -1.0) {                             // fast_vgicp_cuda_impl.hpp:46-52 (RBF mode only)
-    kernel_width_ = kernel_width;
-    kernel_max_dist_ = max_dist <= 0.0 ? kernel_width * 5.0 : max_dist;
+  void setNearestNeighborSearchMethod(NearestNeighborMethod m) { this->cfg_.covariance_method = m == NearestNeighborMethod::GPU_RBF_KERNEL ? PCM_COV_RBF_KERNEL : PCM_COV_KNN; }
+  void setKernelWidth(double kernel_width, double max_dist = -1.0) {                             // fast_vgicp_cuda_impl.hpp:46-52 (read in RBF mode only)
+    this->cfg_.rbf_kernel_width = static_cast<float>(kernel_width);
+    this->cfg_.rbf_max_dist = static_cast<float>(max_dist <= 0.0 ? kernel_width * 5.0 : max_dist);
   }
-
-protected:
-  void computeTransformation(typename GicpRegistration<PointSource, PointTarget>::PointCloudSource& output, const typename GicpRegistration<PointSource, PointTarget>::Matrix4& guess) override {
-    if (rbf_selected_) throw std::runtime_error("pcm_amd::VgicpCudaRegistration: NearestNeighborMethod::GPU_RBF_KERNEL (RBF-kernel covariances) is not built");
-    GicpRegistration<PointSource, PointTarget>::computeTransformation(output, guess);
-  }
-  bool rbf_selected_ = false;
-  double kernel_width_ = 0.25, kernel_max_dist_ = 3.0;                                           // cuda/fast_vgicp_cuda.cu:25-26
 
 public:
   void setNeighborSearchMethod(NeighborSearchMethod m, double radius = -1.0) { detail::set_search_method(this->cfg_, m, radius); }

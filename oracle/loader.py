@@ -23,7 +23,8 @@ class OracleConfig(C.Structure):
                 ("min_knn", C.c_int), ("max_range", C.c_double), ("plane_threshold", C.c_double),
                 ("max_corr_dist", C.c_double), ("k_correspondences", C.c_int),
                 ("regularization", C.c_int), ("num_threads", C.c_int), ("map_capacity", C.c_long),
-                ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double), ("voxel_mode", C.c_int)]
+                ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double), ("voxel_mode", C.c_int),
+                ("rbf_kernel_width", C.c_double), ("rbf_max_dist", C.c_double)]
 
 
 class LioState(C.Structure):
@@ -38,7 +39,7 @@ class OracleResult(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libpcm_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".cpp"))]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so

@@ -201,7 +201,56 @@ static void regularize_f(int method, float c[9]) {
   for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) c[a * 3 + b] = (VD[a * 3 + 0] * Vi[0 * 3 + b] + VD[a * 3 + 1] * Vi[1 * 3 + b]) + VD[a * 3 + 2] * Vi[2 * 3 + b];
 }
 
+/* covariance_estimation_rbf  (/root/reference/src/pointcloud_match/fast_gicp/src/fast_gicp/cuda/covariance_estimation_rbf.cu:59-151):
+ * every point sums over the whole cloud, in blocks of 512 points of the input order (the last block padded with points at the
+ * origin, :126-129), w = expf(-kernel_width * |x - p|^2) for |x - p|^2 <= max_dist^2 (:76-82), one float accumulator per block
+ * (:41-45), the blocks added in order (:108-111), finalize (:47-53), covariance_regularization (fast_vgicp_cuda.cu:210,218).
+ * Plain O(N^2) as the reference runs it.  Not bit-comparable with the real reference (CUDA's expf and nvcc's fused multiply-adds
+ * are not restated): "parity unpinned"; pinned here against a float64 statement of the same sums (tests/test_gpu_rbf.py). */
+static void rbf_covariances_f(const oracle *o, const orc_cloud *c, float *covs) {
+  const float exp_factor = (float)o->cfg.rbf_kernel_width, max_dist = (float)o->cfg.rbf_max_dist;   /* thrust::device_vector<float> constants  :118-121 */
+  const float max_dist_sq = max_dist * max_dist;
+  const long n = c->n, nblocks = (n + 511) / 512;
+#ifdef _OPENMP
+  const int nth = o->cfg.num_threads > 0 ? o->cfg.num_threads : omp_get_max_threads();
+#else
+  const int nth = 1;
+#endif
+#pragma omp parallel for num_threads(nth) schedule(dynamic, 16)
+  for (long i = 0; i < n; i++) {
+    const float *x = c->xyz + 3 * i;
+    float sw = 0.f, sm[3] = {0, 0, 0}, sc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long b = 0; b < nblocks; b++) {
+      float w0 = 0.f, m0[3] = {0, 0, 0}, c0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (long j = 0; j < 512; j++) {
+        const long k = b * 512 + j;
+        float pj[3] = {0.f, 0.f, 0.f};
+        if (k < n) { pj[0] = c->xyz[3 * k]; pj[1] = c->xyz[3 * k + 1]; pj[2] = c->xyz[3 * k + 2]; }
+        const float dx = x[0] - pj[0], dy = x[1] - pj[1], dz = x[2] - pj[2];
+        const float sq_d = (dx * dx + dy * dy) + dz * dz;
+        if (sq_d > max_dist_sq) continue;
+        const float w = expf(-exp_factor * sq_d);
+        w0 += w;
+        for (int a = 0; a < 3; a++) {
+          const float wp = w * pj[a];
+          m0[a] += wp;
+          for (int q = 0; q < 3; q++) c0[a * 3 + q] += wp * pj[q];
+        }
+      }
+      sw += w0;
+      for (int a = 0; a < 3; a++) sm[a] += m0[a];
+      for (int a = 0; a < 9; a++) sc[a] += c0[a];
+    }
+    float mean[3], cov[9];
+    for (int a = 0; a < 3; a++) mean[a] = sm[a] / sw;
+    for (int a = 0; a < 3; a++) for (int q = 0; q < 3; q++) cov[a * 3 + q] = (sc[a * 3 + q] - mean[a] * sm[q]) / sw;
+    regularize_f(o->cfg.regularization, cov);
+    memcpy(covs + 9 * i, cov, sizeof(cov));
+  }
+}
+
 void orc_calc_covariances_f(const oracle *o, const orc_cloud *c, float *covs /* 9 per point */) {
+  if (o->cfg.rbf_kernel_width > 0.0) { rbf_covariances_f(o, c, covs); return; }
   orc_grid g;
   memset(&g, 0, sizeof(g));
   grid_build(&g, c, o->cfg.voxel_resolution);

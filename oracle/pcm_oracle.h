@@ -52,6 +52,8 @@ typedef struct orc_config {
   double ndt_step_size;       /* ndt_omp_impl.hpp:48 step_size_ 0.1 (More-Thuente maximum step) */
   double ndt_outlier_ratio;   /* ndt_omp_impl.hpp:48 outlier_ratio_ 0.55 */
   int voxel_mode;             /* VGICP VoxelAccumulationMode: 0 ADDITIVE (fast_vgicp_impl.hpp:25), 1 ADDITIVE_WEIGHTED, 2 MULTIPLICATIVE */
+  double rbf_kernel_width;    /* VGICP_CUDA: > 0 selects NearestNeighborMethod::GPU_RBF_KERNEL (cuda/covariance_estimation_rbf.cu); fast_vgicp_cuda.cu:25 0.25 */
+  double rbf_max_dist;        /* fast_vgicp_cuda.cu:26 3.0 */
 } orc_config;
 
 typedef struct orc_result {

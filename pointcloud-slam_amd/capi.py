@@ -21,9 +21,8 @@ PCM_ABI_VERSION = 3   # include/pcm_amd.h
 PCM_OK = 0
 PCM_FLAG_NO_LDS_STAGING = 1
 PCM_FLAG_FUSED_STEP = 2
-PCM_FLAG_LEGACY_SEARCH = 8            # round-2 search kernel (A/B)
+PCM_FLAG_COUNTED_SEARCH = 8           # k_linearize_counted instead of k_linearize (A/B; same results, measured slower)
 PCM_FLAG_REFERENCE_KNN_ORDER = 32      # neighbours in the order of libstdc++'s std::nth_element (the reference's), slower kernel
-PCM_FLAG_NO_PLANE_MEMO = 16           # fit every plane in every pass (A/B)
 PCM_FLAG_LIO_REFERENCE_SEMANTICS = 4   # pcm_obs_model keeps LaserMapping's per-point members across calls and scans
 PCM_ERR_NOT_CONVERGED = -6
 PCM_ERR_INTERNAL = -7
@@ -48,7 +47,8 @@ class PcmConfig(C.Structure):
                 ("max_corr_dist", C.c_float), ("k_correspondences", C.c_int32),
                 ("regularization", C.c_int32), ("sort_source", C.c_int32), ("flags", C.c_int32),
                 ("map_capacity", C.c_int32), ("ndt_step_size", C.c_float), ("ndt_outlier_ratio", C.c_float),
-                ("batch_window", C.c_int32), ("voxel_mode", C.c_int32), ("neighbor_search_radius", C.c_float)]
+                ("batch_window", C.c_int32), ("voxel_mode", C.c_int32), ("neighbor_search_radius", C.c_float),
+                ("covariance_method", C.c_int32), ("rbf_kernel_width", C.c_float), ("rbf_max_dist", C.c_float)]
 
 
 class PcmResult(C.Structure):
@@ -71,8 +71,7 @@ class PcmStats(C.Structure):
                 ("candidates", C.c_uint64), ("slots_probed", C.c_uint64), ("linearize_ms", C.c_double),
                 ("target_voxels", C.c_uint64), ("target_slots", C.c_uint64), ("tiles", C.c_uint64),
                 ("tiles_lds_grid", C.c_uint64), ("tiles_lds_points", C.c_uint64), ("residual_ms", C.c_double),
-                ("timed_launches", C.c_uint64), ("timed_pair_slots", C.c_uint64), ("launched_pair_slots", C.c_uint64),
-                ("planes_wanted", C.c_uint64), ("planes_fitted", C.c_uint64)]
+                ("timed_launches", C.c_uint64), ("timed_pair_slots", C.c_uint64), ("launched_pair_slots", C.c_uint64)]
 
 
 def library_path() -> str:

@@ -786,6 +786,128 @@ int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int reg
   return PCM_OK;
 }
 
+// ---------------------------------------------------------------------------
+// RBF-kernel covariances of the CUDA core: NearestNeighborMethod::GPU_RBF_KERNEL of FastVGICPCuda
+// (/root/reference/src/pointcloud_match/fast_gicp/src/fast_gicp/cuda/covariance_estimation_rbf.cu:59-151, selected at
+//  include/fast_gicp/gicp/impl/fast_vgicp_cuda_impl.hpp:107,136, constants fast_vgicp_cuda.cu:25-26,205-219).
+// Every point x sums over ALL points p of its cloud the weights w = expf(-kernel_width * |x - p|^2) of those within max_dist:
+// sum w, sum w p, sum (w p) p^T in float; cov = (sum (w p) p^T - mean (sum w p)^T) / sum w, then covariance_regularization.
+// The reference walks the cloud in blocks of 512 points in INPUT order (the last block padded with points at the origin, which
+// take part like any other point), one accumulator per (point, block), and adds the block accumulators in block order; that
+// order is kept here because float sums are being compared.  What is not kept is the O(N^2) of it: a block of the input order is a
+// compact piece of the sensor's sweep (or of a map tile), so a block whose bounding box lies farther than max_dist from every
+// point of a workgroup is skipped -- its accumulators are exactly zero in the reference too (the `continue` at :77-79).
+// No MFMA: the contraction would be sum_p W[x][p] * F[p][10] with W produced on the fly, in f32 (the 1e-3 eigenvalue floor of the
+// regularisation does not survive bf16 moments), and f32 MFMA runs at the vector rate on gfx950 -- the cull is worth 10x, the
+// matrix pipe nothing.
+// ---------------------------------------------------------------------------
+constexpr int kRbfBlock = 512;   // covariance_estimation_kernel::BLOCK_SIZE  :61
+
+// bounding box of every block of the input order (padding points at the origin included for the last block)
+__global__ void __launch_bounds__(64) k_rbf_block_bounds(const float4* __restrict__ in, uint32_t n, float* __restrict__ bounds /* [blocks][6] */) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  for (uint32_t j = lane; j < (uint32_t)kRbfBlock; j += 64) {
+    const uint32_t i = b * kRbfBlock + j;
+    const float4 p = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+    hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64)); }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bounds[b * 6 + a] = lo[a]; bounds[b * 6 + 3 + a] = hi[a]; }
+  }
+}
+
+// grid = ceil(M / 256): one lane per point of the MAP order (the covariances are stored in that order), the sums over the INPUT order
+__global__ void __launch_bounds__(256) k_covariances_rbf(const float4* __restrict__ map_pts, uint32_t m, const float4* __restrict__ in, uint32_t n, const float* __restrict__ bounds,
+                                                         uint32_t nblocks, float exp_factor, float max_dist, int reg, double* __restrict__ out) {
+  __shared__ float4 s_p[kRbfBlock];
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  const bool live = p < m;
+  const float4 xq = live ? map_pts[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float x[3] = {xq.x, xq.y, xq.z};
+  const float max_dist_sq = max_dist * max_dist;   // :73
+  float sw = 0.f, sm[3] = {0.f, 0.f, 0.f}, sc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // sum over the blocks, in block order (finalization_kernel :108-111)
+  for (uint32_t b = 0; b < nblocks; b++) {
+    // can any point of this block be within max_dist of this lane's point?  (conservative: a little slack for the float compare)
+    float d2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float lo = bounds[b * 6 + a], hi = bounds[b * 6 + 3 + a];
+      const float g = fmaxf(fmaxf(lo - x[a], x[a] - hi), 0.f);
+      d2 += g * g;
+    }
+    const bool need = live && d2 <= max_dist_sq * 1.0001f + 1e-12f;
+    if (!__syncthreads_or(need ? 1 : 0)) continue;   // the whole workgroup skips the block: its accumulators are zero
+#pragma unroll
+    for (int r = 0; r < kRbfBlock / 256; r++) {
+      const uint32_t j = threadIdx.x + 256u * r, i = b * kRbfBlock + j;
+      s_p[j] = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);   // padding  :126-129
+    }
+    __syncthreads();
+    float w0 = 0.f, m0[3] = {0.f, 0.f, 0.f}, c0[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // NormalDistribution::zero()
+    if (need) {
+      for (int j = 0; j < kRbfBlock; j++) {
+        const float4 q = s_p[j];
+        const float dx = x[0] - q.x, dy = x[1] - q.y, dz = x[2] - q.z;
+        const float sq_d = (dx * dx + dy * dy) + dz * dz;          // (x - points[i]).squaredNorm()  :76
+        if (sq_d > max_dist_sq) continue;                          // :77-79
+        const float w = expf(-exp_factor * sq_d);                  // :81
+        const float pj[3] = {q.x, q.y, q.z};
+        w0 += w;                                                   // accumulate  :41-45
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const float wp = w * pj[a];
+          m0[a] += wp;
+#pragma unroll
+          for (int c = 0; c < 3; c++) c0[a * 3 + c] += wp * pj[c];
+        }
+      }
+    }
+    sw += w0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) sm[a] += m0[a];
+#pragma unroll
+    for (int a = 0; a < 9; a++) sc[a] += c0[a];
+    __syncthreads();   // the block's points are through before the next block overwrites them
+  }
+  if (!live) return;
+  // finalize  :47-53
+  float mean[3], cov[9];
+#pragma unroll
+  for (int a = 0; a < 3; a++) mean[a] = sm[a] / sw;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) cov[a * 3 + c] = (sc[a * 3 + c] - mean[a] * sm[c]) / sw;
+  }
+  regularize_cov_f(reg, cov);   // covariance_regularization  fast_vgicp_cuda.cu:210,218
+  float* o = reinterpret_cast<float*>(out + (size_t)p * 6);   // the float 3x3 in the point's 6-double slot, like k_covariances with reg >= 16
+#pragma unroll
+  for (int a = 0; a < 9; a++) o[a] = cov[a];
+}
+
+int compute_covariances_rbf(hipStream_t stream, const TargetMap& map, const float4* d_input_order, uint32_t n, double kernel_width, double max_dist, int regularization, double* d_out,
+                            std::string* err) {
+  if (!(kernel_width > 0.0) || !(max_dist > 0.0)) { *err = "rbf_kernel_width and rbf_max_dist must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
+  const uint32_t nblocks = (n + kRbfBlock - 1) / kRbfBlock;
+  float* bounds = nullptr;
+  if (hipMallocAsync(reinterpret_cast<void**>(&bounds), sizeof(float) * 6 * nblocks, stream) != hipSuccess) { *err = "hipMallocAsync(rbf block bounds)"; return PCM_ERR_HIP; }
+  k_rbf_block_bounds<<<nblocks, 64, 0, stream>>>(d_input_order, n, bounds);
+  // thrust::device_vector<float> constants: the doubles are narrowed once  :118-121
+  k_covariances_rbf<<<(map.num_points + 255) / 256, 256, 0, stream>>>(map.pts, map.num_points, d_input_order, n, bounds, nblocks, (float)kernel_width, (float)max_dist, regularization, d_out);
+  const hipError_t e = hipGetLastError();
+  (void)hipFreeAsync(bounds, stream);
+  if (e != hipSuccess) { *err = std::string("k_covariances_rbf: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
+  return PCM_OK;
+}
+
 // GaussianVoxelMap::create_voxelmap(points, covariances) of the CUDA core: voxel mean = mean of its points, voxel covariance =
 // mean of the point covariances (gaussian_voxelmap.cu:75-169); sums in double, input order (the reference: float atomics)
 __global__ void __launch_bounds__(128) k_vgc_voxels(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, const double* __restrict__ covs, uint32_t nvox,

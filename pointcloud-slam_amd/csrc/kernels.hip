@@ -321,14 +321,9 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
       const int big = 0x3fffffff;
       int mn[3] = {search ? cx : big, search ? cy : big, search ? cz : big};
       int mx[3] = {search ? cx : -big, search ? cy : -big, search ? cz : -big};
+      // wave reductions on the DPP path (linearize_common.h): 36 ds_bpermute round trips less per tile
   #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-  #pragma unroll
-        for (int a = 0; a < 3; a++) {
-          mn[a] = min(mn[a], __shfl_xor(mn[a], off, 64));
-          mx[a] = max(mx[a], __shfl_xor(mx[a], off, 64));
-        }
-      }
+      for (int a = 0; a < 3; a++) { mn[a] = wave_min_i32(mn[a]); mx[a] = wave_max_i32(mx[a]); }
       if (lane == 0) {
   #pragma unroll
         for (int a = 0; a < 3; a++) { s_red[wave][a] = mn[a]; s_red[wave][3 + a] = mx[a]; }
@@ -395,12 +390,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
           // voxel coordinates of the brick's corner relative to the tile box
           s_borg[lane] = make_int4(((bx0 + x) << kBrickShift) - ox0, ((by0 + y) << kBrickShift) - oy0, ((bz0 + z) << kBrickShift) - oz0, 0);
         }
-        uint32_t incl = npts;
-  #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t v = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += v;
-        }
+        const uint32_t incl = scan_add_wave(npts);
         if (lane < nb) { s_bps[lane] = ps; s_boff[lane] = incl - npts; }
         if (lane == 63) s_boff[kCapBricks] = incl;   // total
       }
@@ -415,12 +405,12 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
         // ---- stage the bricks' map points through LDS: flat, coalesced, all loads in flight --------
         float4 v[kCapPts / 256];
         int vb[kCapPts / 256];
+        int b = 0;   // brick of staged point k: k grows with r, so the brick index only moves forward
   #pragma unroll
         for (int r = 0; r < kCapPts / 256; r++) {
           const uint32_t k = threadIdx.x + 256u * r;
           vb[r] = -1;
           if (k < total) {
-            int b = 0;
             while (b + 1 < nb && s_boff[b + 1] <= k) b++;   // nb is small (typically 1..8)
             vb[r] = b;
             v[r] = gload4(tg.pts + s_bps[b] + (k - s_boff[b]));
@@ -673,6 +663,11 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
       for (int g = 0; g < 8; g++) v += s_grp[g * kLioStride + threadIdx.x];
       gstore_d(d.partials + (size_t)tile_x * kLioStride + threadIdx.x, v);
     }
+  } else if constexpr (!FUSED) {
+    // residual / Jacobian rows as doubles in LDS, 29 sums of the tile (linearize_common.h): the same products and the same order of
+    // additions as the float rows this kernel wrote before, with 8 conversions per lane instead of 64 in the reduction loop
+    static_assert(sizeof(float4) * kCapPts >= (size_t)kReduceLdsBytes, "the reduction rows alias the staged points");
+    residual_and_reduce<WRITE_PLANES>(d, i, tile_x, live, pl, q, pn_body, s_pts);
   } else {
     // ---- residual / Jacobian of this lane's point -> one 8-float row in LDS ---------------------------
     // (the LDS of s_pts is free now: nobody reads map points after the barrier above)
@@ -762,6 +757,7 @@ __global__ void __launch_bounds__(256, 5) k_linearize(const PairDesc* __restrict
         finish_pair_in_place(d, const_cast<PairState*>(states), pair, lp, nblocks, flags_row, f_grp, f_tot);
       }
     }
+  
   }
   PCM_STAMP(6)   // queued double-precision fits + residual + workgroup reduction
   if (TIMING && threadIdx.x == 0) atomicAdd(&stats[15], 1ull);

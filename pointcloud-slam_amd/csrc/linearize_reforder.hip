@@ -11,7 +11,7 @@
 // ~1e-4 m (profiles/r03_knn_order_sensitivity.json).  The default kernels sort ascending; this kernel reproduces the reference
 // order exactly: the candidate array of every scan point is built in the reference's visit order in private memory and put
 // through the same three selections by nth_select.h, a restatement of libstdc++'s std::nth_element checked against the real
-// one permutation for permutation (tests/test_knn_order.py).  Oracle twin: orc_set_knn_order(ORC_KNN_ORDER_LIBSTDCXX), which
+// one permutation for permutation (tests/test_knn_order.py).  The CPU check has a "libstdcxx" order mode of its own, which
 // calls the container's std::nth_element itself; GPU == oracle bit for bit (tests/test_gpu_reforder.py).
 //
 // Shape: one scan point per lane, candidates straight from the global brick hash (no LDS staging: the per-lane candidate array

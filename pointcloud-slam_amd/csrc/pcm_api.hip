@@ -172,6 +172,10 @@ int validate_config(pcm_ctx* c, const pcm_config& g) {
     if (!(g.max_corr_dist > 0.f)) { c->err = "max_corr_dist must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
     if (g.voxel_mode < 0 || g.voxel_mode > 2) { c->err = "voxel_mode must be 0 (ADDITIVE), 1 (ADDITIVE_WEIGHTED) or 2 (MULTIPLICATIVE)"; return PCM_ERR_INVALID_ARGUMENT; }
   }
+  if (g.covariance_method != PCM_COV_KNN) {
+    if (g.covariance_method != PCM_COV_RBF_KERNEL || g.model != PCM_MODEL_VGICP_CUDA) { c->err = "covariance_method: PCM_COV_RBF_KERNEL is a mode of VGICP_CUDA (NearestNeighborMethod::GPU_RBF_KERNEL)"; return PCM_ERR_INVALID_ARGUMENT; }
+    if (!(g.rbf_kernel_width > 0.f) || !(g.rbf_max_dist > 0.f)) { c->err = "rbf_kernel_width and rbf_max_dist must be > 0"; return PCM_ERR_INVALID_ARGUMENT; }
+  }
   if (g.neighbor_search_radius != 0.f) {   // NeighborSearchMethod::DIRECT_RADIUS: "supported on only VGICP_CUDA" (gicp_settings.hpp:8) and NDTCuda
     if (!radius_model(g.model)) { c->err = "neighbor_search_radius (DIRECT_RADIUS) is a mode of NDT_P2D / NDT_D2D / VGICP_CUDA"; return PCM_ERR_INVALID_ARGUMENT; }
     if (!(g.neighbor_search_radius > 0.f) || g.neighbor_search_radius > 3.f) { c->err = "neighbor_search_radius must be in (0, 3] voxels"; return PCM_ERR_INVALID_ARGUMENT; }
@@ -263,9 +267,13 @@ int prepare(pcm_ctx* c) {
   }
   if (gicp) {
     // FastGICP::computeTransformation: covariances of both clouds, lazily   fast_gicp_impl.hpp:102-110
-    if (c->cov_k != c->cfg.k_correspondences || c->cov_reg != c->cfg.regularization + 100 * c->cfg.model || c->cov_vmode != c->cfg.voxel_mode) {
+    const bool rbf = c->cfg.model == PCM_MODEL_VGICP_CUDA && c->cfg.covariance_method == PCM_COV_RBF_KERNEL;   // NearestNeighborMethod::GPU_RBF_KERNEL
+    const float rbf_w = rbf ? c->cfg.rbf_kernel_width : -1.f, rbf_d = rbf ? c->cfg.rbf_max_dist : -1.f;
+    if (c->cov_k != c->cfg.k_correspondences || c->cov_reg != c->cfg.regularization + 100 * c->cfg.model || c->cov_vmode != c->cfg.voxel_mode || c->cov_rbf_w != rbf_w ||
+        c->cov_rbf_d != rbf_d) {
       c->src_cov_valid = false; c->tgt_cov_valid = false;
       c->cov_k = c->cfg.k_correspondences; c->cov_reg = c->cfg.regularization + 100 * c->cfg.model; c->cov_vmode = c->cfg.voxel_mode;
+      c->cov_rbf_w = rbf_w; c->cov_rbf_d = rbf_d;
     }
     // the scan's own grid is only the index of its kNN search: a finer cell keeps the candidate lists short where a
     // LiDAR scan is dense (near the sensor one 0.5 m voxel holds thousands of points)
@@ -288,7 +296,8 @@ int prepare(pcm_ctx* c) {
       // `if (target_covs_.size() != target_->size()) calculate_covariances(...)`  fast_gicp_impl.hpp:107-109
       const bool given = c->cfg.model != PCM_MODEL_VGICP_CUDA && c->user_cov[1].size() == (size_t)c->map.num_points * 6 && c->map.num_points == c->tgt.n;
       int rc = given ? upload_covariances(c->stream, c->map, c->user_cov[1].data(), c->tgt_cov, &c->err)
-                     : compute_covariances(c->stream, c->map, c->cfg.k_correspondences, reg_code, c->tgt_cov, &c->err);
+               : rbf   ? compute_covariances_rbf(c->stream, c->map, c->tgt.d_pts, (uint32_t)c->tgt.n, c->cfg.rbf_kernel_width, c->cfg.rbf_max_dist, c->cfg.regularization, c->tgt_cov, &c->err)
+                       : compute_covariances(c->stream, c->map, c->cfg.k_correspondences, reg_code, c->tgt_cov, &c->err);
       if (rc != PCM_OK) return rc;
       if (c->cfg.model == PCM_MODEL_VGICP_CUDA) {
         if (c->cvox_cap < c->map.num_voxels) {
@@ -321,7 +330,8 @@ int prepare(pcm_ctx* c) {
       }
       const bool given = c->cfg.model != PCM_MODEL_VGICP_CUDA && c->user_cov[0].size() == (size_t)c->srcmap.num_points * 6 && c->srcmap.num_points == c->src.n;   // :104-106
       int rc = given ? upload_covariances(c->stream, c->srcmap, c->user_cov[0].data(), c->src_cov, &c->err)
-                     : compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0), c->src_cov, &c->err);
+               : rbf   ? compute_covariances_rbf(c->stream, c->srcmap, c->src.d_pts, (uint32_t)c->src.n, c->cfg.rbf_kernel_width, c->cfg.rbf_max_dist, c->cfg.regularization, c->src_cov, &c->err)
+                       : compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0), c->src_cov, &c->err);
       if (rc != PCM_OK) return rc;
       c->src_cov_valid = true;
     }
@@ -367,10 +377,8 @@ int prepare(pcm_ctx* c) {
   }
   if (c->planes_cap < c->src.n) {
     if (c->planes) hipFree(c->planes);
-    if (c->fitcache) hipFree(c->fitcache);
-    c->planes = nullptr; c->fitcache = nullptr; c->planes_cap = 0;
+    c->planes = nullptr; c->planes_cap = 0;
     HIPCK(c, hipMalloc(&c->planes, sizeof(float4) * c->src.n));
-    HIPCK(c, hipMalloc(&c->fitcache, sizeof(float4) * c->src.n));
     c->planes_cap = c->src.n;
   }
   return PCM_OK;
@@ -418,7 +426,6 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->corr = c->corr;
   d->nn = c->nn;
   d->planes = c->planes;
-  d->fitcache = c->fitcache;
   d->partials = partials;
   d->counter = c->counter;
 }
@@ -443,7 +450,6 @@ KernelParams kernel_params(const pcm_config& g, const Geom& geom) {
   kp.points_per_block = geom.points_per_block;
   kp.tiles_per_pair = geom.tiles_per_pair;
   kp.use_lds = (g.flags & PCM_FLAG_NO_LDS_STAGING) ? 0 : 1;
-  kp.plane_cache = (g.flags & PCM_FLAG_NO_PLANE_MEMO) ? 0 : 1;
   kp.do_step = 1;
   kp.lin_points_per_block = (is_ndt(g.model) || g.model == PCM_MODEL_VGICP_CUDA) ? geom.points_per_block : 256;
   kp.coord_mode = coord_mode_for(g.model);
@@ -578,7 +584,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   if (counters_on) HIPCK(c0, hipMemsetAsync(w->d_stats, 0, sizeof(unsigned long long) * 16, st));
   const bool is_lm = g.optimizer == PCM_OPT_LEVENBERG_MARQUARDT;
   const bool write_sel = is_lm;  // trial passes re-use the planes of the selected set
-  const bool legacy_search = (g.flags & PCM_FLAG_LEGACY_SEARCH) != 0;   // the round-2 per-cell search kernel (A/B)
+  const bool counted_search = (g.flags & PCM_FLAG_COUNTED_SEARCH) != 0;   // k_linearize_counted (A/B)
   const bool ref_order = g.model == PCM_MODEL_P2PLANE && (g.flags & PCM_FLAG_REFERENCE_KNN_ORDER) != 0;   // neighbours in libstdc++'s nth_element order
   if (ref_order) {
     for (int i = 0; i < n; i++) {
@@ -624,7 +630,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
     else if (ref_order) launch_linearize_reforder(st, w->d_descs, w->d_states, kpr, nl, write_sel);
-    else if (!legacy_search) launch_linearize_flat(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
+    else if (counted_search) launch_linearize_counted(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (timed) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
     if (!fuse) launch_finish_round(st, w->d_descs, w->d_states, kpr, lp, nl, false, !is_lm, w->d_flags + (size_t)r * n, w->d_sums, use_list ? nullptr : w->d_queue, n);
@@ -684,8 +690,6 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     c0->stats.tiles += hs[3];
     c0->stats.tiles_lds_grid += hs[4];
     c0->stats.tiles_lds_points += hs[2];
-    c0->stats.planes_wanted += hs[5];
-    c0->stats.planes_fitted += hs[6];
   }
   if (stats_on) {
     double ms = 0.0, ms2 = 0.0;
@@ -741,7 +745,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
     if (c->map.max_voxel_points > (uint32_t)kRefMaxVoxelPoints) { c->err = "PCM_FLAG_REFERENCE_KNN_ORDER supports at most " + std::to_string(kRefMaxVoxelPoints) + " points per voxel"; return PCM_ERR_UNSUPPORTED; }
     launch_linearize_reforder(c->stream, w->d_descs, w->d_states, kp1, 1, true);
   }
-  else if (linearize && !(c->cfg.flags & PCM_FLAG_LEGACY_SEARCH)) launch_linearize_flat(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr);
+  else if (linearize && (c->cfg.flags & PCM_FLAG_COUNTED_SEARCH)) launch_linearize_counted(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
   launch_finish_round(c->stream, w->d_descs, w->d_states, kp1, lsq_params(c->cfg), 1, !linearize, false, w->d_flags, w->d_sums);
@@ -969,6 +973,9 @@ void pcm_default_config(pcm_config* cfg) {
   cfg->map_capacity = 1000000;   // IVox Options::capacity_  ivox3d.h:57
   cfg->ndt_step_size = 0.1f;     // ndt_omp_impl.hpp:48
   cfg->ndt_outlier_ratio = 0.55f;
+  cfg->covariance_method = PCM_COV_KNN;
+  cfg->rbf_kernel_width = 0.25f;   // FastVGICPCudaCore  fast_vgicp_cuda.cu:25-26
+  cfg->rbf_max_dist = 3.0f;
 }
 
 pcm_ctx* pcm_create(int device, const pcm_config* cfg) {
@@ -1027,7 +1034,6 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->ndt_out) hipFree(c->ndt_out);
     if (c->ndt_out_host) hipHostFree(c->ndt_out_host);
     if (c->planes) hipFree(c->planes);
-    if (c->fitcache) hipFree(c->fitcache);
     if (c->counter) hipFree(c->counter);
     if (c->nn) hipFree(c->nn);
     free_ws(c);

@@ -196,9 +196,8 @@ struct PairDesc {
   TargetView tgt;
   SourceView src;
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
-  float4* fitcache;     // N: plane memo of k_linearize_flat: esti_plane's result for the neighbour tuple kept in nn (x = NaN: rejected)
   LioPose lio;          // LIO measurement model only
-  uint32_t* nn;         // LIO: [N][5] neighbour indices into tgt.pts (~0u: none) from the last matching call; P2PLANE: the tuple of the plane memo
+  uint32_t* nn;         // LIO: [N][5] neighbour indices into tgt.pts (~0u: none) from the last matching call
   float2* lio_aux;      // LIO reference semantics: residuals_[i] (.x) and point_selected_surf_[i] (.y != 0) in the caller's scan order
   int32_t* corr;        // NDT / VGICP: [elements][offsets] matched target voxel (or -1) of the last linearize; GICP: [N] matched target point
   const double* src_cov;   // GICP / VGICP: [N][6] regularised covariance of every source point (xx xy xz yy yz zz)
@@ -252,8 +251,6 @@ struct KernelParams {
   int32_t use_list;           // 1: the grid's pair axis indexes `active` (only pairs the host still believes active are launched)
   uint8_t active[kMaxListedPairs];   // pair index of each grid entry (batches of <= kMaxListedPairs pairs; indices < 256)
   double max_corr_sq;         // GICP: corr_dist_threshold_^2 (double, as pcl::Registration holds it)
-  int32_t plane_cache;        // k_linearize_flat: 1 = memoise the plane of a point's ordered neighbour tuple across the linearize passes of one align
-  int32_t pad_kp;
 };
 
 }  // namespace pcm

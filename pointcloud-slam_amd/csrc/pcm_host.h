@@ -105,7 +105,7 @@ struct LaunchGeom {
 };
 void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                       unsigned long long* d_stats, bool timing);
-void launch_linearize_flat(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
+void launch_linearize_counted(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                            unsigned long long* d_stats, bool timing = false);
 void launch_linearize_reforder(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);
 void launch_linearize_fused(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, unsigned char* d_flags_row);
@@ -120,6 +120,9 @@ void launch_fitness(hipStream_t stream, const TargetView& tg, int coord_mode, co
 void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
 int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err);
+// RBF-kernel covariances of the CUDA core (GPU_RBF_KERNEL): map order out, sums over the input order
+int compute_covariances_rbf(hipStream_t stream, const TargetMap& map, const float4* d_input_order, uint32_t n, double kernel_width, double max_dist, int regularization, double* d_out,
+                            std::string* err);
 int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, int mode, VgVoxel* d_out, std::string* err);
 int build_vgc_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgcVoxel* d_out, std::string* err);
 // pclndt.hip: pclomp NDT leaves and derivative passes (pass 0: score+gradient+Hessian, 1: score+gradient, 2: double Hessian only)
@@ -152,6 +155,7 @@ struct pcm_ctx {
   size_t src_cov_cap = 0, tgt_cov_cap = 0;
   bool src_cov_valid = false, tgt_cov_valid = false;
   int cov_k = 0, cov_reg = -1, cov_vmode = -1;
+  float cov_rbf_w = -1.f, cov_rbf_d = -1.f;   // RBF parameters the cached covariances were computed with (-1: kNN covariances)
   pcm::VgVoxel* vvox = nullptr;
   size_t vvox_cap = 0;
   pcm::VgcVoxel* cvox = nullptr;   // VGICP_CUDA
@@ -170,7 +174,6 @@ struct pcm_ctx {
   size_t src_order_cap = 0;
   bool src_sorted = false;       // src_order holds the current source
   float4* planes = nullptr;
-  float4* fitcache = nullptr;    // plane memo of k_linearize_flat (with nn), same capacity as planes
   unsigned int* counter = nullptr;   // round tickets (device, one word)
   size_t planes_cap = 0;
   std::string err;

@@ -378,6 +378,15 @@ class VgicpCudaRegistration(Registration):
     model = "VGICP_CUDA"
     defaults = {"voxel_resolution": 1.0, "num_neighbors": 1}
 
+    def set_nearest_neighbor_search_method(self, method: str):
+        """setNearestNeighborSearchMethod (fast_vgicp_cuda_impl.hpp:64-66): "CPU_PARALLEL_KDTREE" / "GPU_BRUTEFORCE" (exact kNN
+        covariances) or "GPU_RBF_KERNEL" (cuda/covariance_estimation_rbf.cu)."""
+        self._set(covariance_method=1 if method == "GPU_RBF_KERNEL" else 0)
+
+    def set_kernel_width(self, kernel_width: float, max_dist: float = -1.0):
+        """setKernelWidth (fast_vgicp_cuda_impl.hpp:46-52): max_dist defaults to 5 x kernel_width."""
+        self._set(rbf_kernel_width=float(kernel_width), rbf_max_dist=float(kernel_width * 5.0 if max_dist <= 0 else max_dist))
+
 
 class NdtRegistration(Registration):
     """NDT on Gaussian voxels with the reference NDTCuda's semantics

@@ -1,8 +1,6 @@
-"""k_linearize_flat (flat candidate lists, compacted plane fits, plane memo) against the round-2 search kernel and the oracle.
-
-The flat kernel must pick the same neighbours in the same order as the per-cell walk (jueying_lio ivox3d.h:132-204) and
-therefore produce bit-identical planes and sums; the plane memo (a plane re-used when a point's ordered neighbour tuple is
-the one of the previous linearize pass of the same align) must never change a result.  Run on the MI355X box with ``-m gpu``.
+"""k_linearize_counted (counted cells: every candidate's address known up front, four per cell and trip) against the round-2
+default search kernel k_linearize and the oracle: the same neighbours in the same order as the per-cell walk
+(jueying_lio ivox3d.h:132-204), hence bit-identical planes, sums and poses.  Run on the MI355X box with ``-m gpu``.
 """
 import numpy as np
 import pytest
@@ -11,7 +9,7 @@ from helpers import HB_RTOL, POSE_TOL_M, POSE_TOL_RAD, pose_error, rel_err
 
 pytestmark = pytest.mark.gpu
 
-LEGACY, NO_MEMO, NO_LDS = 8, 16, 1
+COUNTED, NO_LDS = 8, 1
 
 
 def _reg(pcm, p_map, p_scan, optimizer="GN", **kw):
@@ -31,11 +29,11 @@ def _same_linearize(a, b, T, n):
 
 @pytest.mark.parametrize("nn", [1, 7, 19, 27])
 @pytest.mark.parametrize("sort_source", [0, 1])
-def test_flat_equals_legacy_linearize(pcm, synth, nn, sort_source):
+def test_counted_equals_default_linearize(pcm, synth, nn, sort_source):
     p = synth.make_pair(3, 12000, 120000)
     n = len(p.scan)
-    a = _reg(pcm, p.submap, p.scan, num_neighbors=nn, sort_source=sort_source)
-    b = _reg(pcm, p.submap, p.scan, num_neighbors=nn, sort_source=sort_source, flags=LEGACY)
+    a = _reg(pcm, p.submap, p.scan, num_neighbors=nn, sort_source=sort_source, flags=COUNTED)
+    b = _reg(pcm, p.submap, p.scan, num_neighbors=nn, sort_source=sort_source)
     for T in (p.T_gt, p.guess.astype(np.float64)):
         if sort_source:   # the device order of the scan is fixed by the first align's guess: same for both objects
             a.align(p.guess); b.align(p.guess)
@@ -43,48 +41,41 @@ def test_flat_equals_legacy_linearize(pcm, synth, nn, sort_source):
 
 
 @pytest.mark.parametrize("optimizer", ["GN", "LM"])
-def test_memo_and_kernels_give_identical_aligns(pcm, synth, optimizer):
-    """Same poses bit for bit with the plane memo, without it, and with the round-2 kernel; single and batched."""
+def test_kernels_give_identical_aligns(pcm, synth, optimizer):
+    """Same poses bit for bit with the default kernel; single and batched; ragged scans whose last tile is partial."""
     pairs = [synth.make_pair(40 + i, 5000 + 2500 * i, 50000 + 20000 * i) for i in range(4)]
     guesses = np.stack([p.guess for p in pairs])
     res = {}
-    for flags in (0, NO_MEMO, LEGACY):
+    for flags in (COUNTED, 0):
         regs = [_reg(pcm, p.submap, p.scan, optimizer, flags=flags) for p in pairs]
         res[flags] = (pcm.align_batch(regs, guesses), [g.align(p.guess) for g, p in zip(regs, pairs)])
-        # a second align of the same objects starts from an empty memo again
-        again = pcm.align_batch(regs, guesses)
-        for x, y in zip(res[flags][0], again):
-            assert np.array_equal(x.T64, y.T64) and x.iterations == y.iterations and x.num_inliers == y.num_inliers
     for k in range(len(pairs)):
-        base = res[LEGACY][0][k]
-        for flags in (0, NO_MEMO):
-            for r in (res[flags][0][k], res[flags][1][k]):
-                assert np.array_equal(r.T64, base.T64) and np.array_equal(r.H, base.H)
-                assert r.iterations == base.iterations and r.num_inliers == base.num_inliers and r.num_linearize == base.num_linearize
-                assert r.num_compute_error == base.num_compute_error and r.cost == base.cost
+        base = res[0][0][k]
+        for r in (res[COUNTED][0][k], res[COUNTED][1][k]):
+            assert np.array_equal(r.T64, base.T64) and np.array_equal(r.H, base.H)
+            assert r.iterations == base.iterations and r.num_inliers == base.num_inliers and r.num_linearize == base.num_linearize
+            assert r.num_compute_error == base.num_compute_error and r.cost == base.cost
 
 
-def test_memo_does_not_survive_a_new_target(pcm, synth):
-    """The memo is keyed by map-point indices: a new map with the same scan must not see the old planes."""
-    p0, p1 = synth.make_pair(50, 6000, 60000), synth.make_pair(51, 6000, 60000)
-    g = _reg(pcm, p0.submap, p0.scan)
-    g.align(p0.guess)
-    g.set_input_target(p1.submap)
-    r = g.align(p0.guess)
-    f = _reg(pcm, p1.submap, p0.scan, flags=NO_MEMO)
-    rf = f.align(p0.guess)
-    assert np.array_equal(r.T64, rf.T64) and r.iterations == rf.iterations and r.num_inliers == rf.num_inliers
+def test_partial_tiles_with_dead_lanes_in_every_position(pcm, synth):
+    """Scan sizes that leave the last tile with 1 ... 255 live lanes: lanes 0..26 of a wave hand the cell offsets to the others
+    through v_readlane whether or not they hold a query point themselves (a first form read registers dead lanes never wrote)."""
+    p = synth.make_pair(44, 2048, 30000)
+    for n in (257, 264, 300, 330, 383, 449, 511, 513, 1000, 2047):
+        a = _reg(pcm, p.submap, p.scan[:n], sort_source=0, flags=COUNTED)
+        b = _reg(pcm, p.submap, p.scan[:n], sort_source=0)
+        _same_linearize(a, b, p.T_gt, n)
 
 
 @pytest.mark.parametrize("m_map,res", [(130000, 0.5), (340000, 0.5), (60000, 2.0)])
 def test_dense_voxels(pcm, synth, m_map, res):
-    """Voxel neighbourhoods with more candidates than a wave's list holds (the run searches the global structures) and voxels
-    with more than 255 points (the tile does): same planes and sums as the round-2 kernel and the global path, oracle parity."""
+    """Voxels with tens to hundreds of points (the batch loop behind the first four candidates of a cell) and voxels with more than
+    255 points (the tile searches the global structures): same planes and sums as the default kernel and the global path, oracle parity."""
     from oracle import Oracle
     sc, sm, T = synth.corner_scene(3000, m_map, seed=5, noise=0.01)
     n = len(sc)
-    a = _reg(pcm, sm, sc, voxel_resolution=res)
-    b = _reg(pcm, sm, sc, voxel_resolution=res, flags=LEGACY)
+    a = _reg(pcm, sm, sc, voxel_resolution=res, flags=COUNTED)
+    b = _reg(pcm, sm, sc, voxel_resolution=res)
     c = _reg(pcm, sm, sc, voxel_resolution=res, flags=NO_LDS)
     o = Oracle("P2PLANE", "GN", voxel_resolution=res, num_neighbors=27); o.set_input_target(sm); o.set_input_source(sc)
     G = T.copy(); G[:3, 3] += [0.03, -0.02, 0.04]
@@ -110,8 +101,8 @@ def test_sparse_and_ragged_tiles(pcm, synth):
     sc[6, :3] = np.nan
     n = len(sc)
     for nn in (7, 27):
-        a = _reg(pcm, p.submap, sc, num_neighbors=nn, sort_source=0)
-        b = _reg(pcm, p.submap, sc, num_neighbors=nn, sort_source=0, flags=LEGACY)
+        a = _reg(pcm, p.submap, sc, num_neighbors=nn, sort_source=0, flags=COUNTED)
+        b = _reg(pcm, p.submap, sc, num_neighbors=nn, sort_source=0)
         o = Oracle("P2PLANE", "GN", voxel_resolution=0.5, num_neighbors=nn); o.set_input_target(p.submap); o.set_input_source(sc)
         for X in (p.T_gt, p.guess.astype(np.float64)):
             _same_linearize(a, b, X, n)

@@ -39,11 +39,11 @@ print("ms per batched align (one stream, scans already ordered): %.3f  -> %.0f r
 regs[0].reset_stats(); regs[0].set_profiling(2)
 res = pcm.align_batch(regs, g)
 st = regs[0].stats(); regs[0].set_profiling(0)
-print('candidates/point %.2f  tiles staged %.3f  planes wanted %d fitted %d (memo answered %.1f %%)' % (st['candidates'] / max(1, st['point_passes']), st['tiles_lds_points'] / max(1, st['tiles']), st['planes_wanted'], st['planes_fitted'], 100.0 * (1 - st['planes_fitted'] / max(1, st['planes_wanted']))))
+print('candidates/point %.2f  tiles staged %.3f' % (st['candidates'] / max(1, st['point_passes']), st['tiles_lds_points'] / max(1, st['tiles'])))
 if a.phases:
     regs[0].set_profiling(4)
     res = pcm.align_batch(regs, g)
     pc = regs[0].phase_cycles()
     n = max(1, pc[7])
-    names = ['load+box', 'probe', 'stage', 'cellgrid', 'search', 'fit', 'jobs+residual+reduce'] if (a.flags & 8) else ['load+box', 'probe', 'stage+grid', 'lists', 'search', 'memo+fits', 'store+residual+reduce']
+    names = ['load+box', 'probe', 'stage+grid', '-', 'search', 'fit', 'jobs+residual+reduce'] if (a.flags & 8) else ['load+box', 'probe', 'stage', 'cellgrid', 'search', 'fit', 'jobs+residual+reduce']
     print('tiles', pc[7]); print({k: round(v / n) for k, v in zip(names, pc[:7])}, 'ticks/tile')

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r03pmc
 mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_flat_search.py -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
+timeout -k 10 600 python -m pytest tests/test_gpu_counted_search.py -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
 python tools/gen_cache.py --pairs 32 > $O/gen.log 2>&1
 pass() { name=$1; flags=$2; sub=$3; shift 3; L="$@";
   rocprofv3 --pmc $L --kernel-trace --output-format csv -d $O/$name -o $name -- python3 tools/prof_single.py --pairs 32 --steps 1 --phases 0 --cache /tmp/pcm_pairs.npz --flags $flags > $O/$name.log 2>&1
