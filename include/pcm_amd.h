@@ -165,6 +165,10 @@ typedef struct pcm_stats {
   uint64_t timed_launches;       /* launches bracketed by HIP events (= linearize_launches unless profiling bit3 samples them) */
   uint64_t timed_pair_slots;     /* sum of the pair-list lengths of the timed launches ... */
   uint64_t launched_pair_slots;  /* ... and of all launches: the share of point_passes that falls to the timed ones */
+  uint64_t lru_batch_hazards;    /* sliding map: voxels a batch touched whose previous touch was older than the batch's eviction cut-off -- the
+                                  * reference's sequential LRU list (ivox3d.h:256-281) may have dropped such a voxel before the batch reached it
+                                  * and re-created it with the batch's points only; the batch rule here keeps it whole.  0 = the map equals the
+                                  * sequential result (a LiDAR map's oldest voxels lie behind the sensor: never observed non-zero) */
 } pcm_stats;
 
 typedef struct pcm_ctx pcm_ctx;
@@ -298,7 +302,7 @@ typedef struct pcm_imu_pose {
 
 /* Motion compensation of a scan into its frame-end pose, in place (x, y, z of every record are rewritten).
  * Replaces the backward-propagation loop of ImuProcess::UndistortPcl (jueying_lio/include/imu_processing.hpp:245-285).
- * `time_offset_bytes`: where the float time stamp of a point [ms] sits in its record (PointXYZINormal::curvature = 40);
+ * `time_offset_bytes`: where the float time stamp of a point [ms] sits in its record (PointXYZINormal::curvature = 36: x y z pad | normal_x normal_y normal_z pad | intensity curvature);
  * points sorted by time (imu_processing.hpp:177-178); `poses`: IMUpose_ (host memory), `end_state`: the propagated state. */
 int pcm_undistort(pcm_ctx *ctx, void *points, size_t n, size_t stride_bytes, size_t time_offset_bytes, int memory, const pcm_imu_pose *poses, int num_poses,
                   const pcm_lio_state *end_state);
@@ -335,6 +339,31 @@ int pcm_gicp_bfgs_update_correspondences(pcm_ctx *ctx, const float *transformati
 /* parity hook: the pairs of the last update (source_indices / target_indices, :466-472) and their 3x3 float matrices (row-major);
  * any pointer may be NULL */
 int pcm_gicp_bfgs_get_correspondences(pcm_ctx *ctx, int32_t *idx_src, int32_t *idx_tgt, float *mahalanobis9, size_t capacity);
+
+/* One LiDAR frame of LaserMapping::Run with the scan resident on the device from the driver message to the map update
+ * (jueying_lio/src/laser_mapping.cc:323-347, 525-583): the hand-offs between the operators above never pass through host memory.
+ *   pcm_lio_frame_begin   raw livox_ros_driver::CustomMsg points (20-byte records, see pcm_livox_filter) -- the ONLY host -> device
+ *                         copy of the frame -- -> AviaHandler filter (pointcloud_preprocess.cc:44-88) -> motion compensation into
+ *                         the frame-end pose (imu_processing.hpp:245-285; skipped when num_poses < 2) -> voxel-grid down-sampling
+ *                         (laser_mapping.cc:323-328; leaf_size 0 = none) -> the result (scan_down_body_) becomes the SOURCE of
+ *                         this object; *n_scan = its size.  The reference sorts the scan by time before compensating it
+ *                         (imu_processing.hpp:177-178); the message order is kept here (a point's compensation depends on its own
+ *                         stamp only and a Livox message is time-ordered).
+ *   pcm_obs_model x k     the IEKF of the caller between the calls (esekfom.hpp:1685-1735), as before
+ *   pcm_lio_frame_end     = pcm_map_incremental with the updated state: add-filter + AddPoints, the map stays on the device
+ * Target = the map (pcm_set_target once, then it slides by itself). */
+typedef struct pcm_lio_frame_params {
+  int32_t num_scans;         /* 6   config/livox.yaml:8  scan_line */
+  int32_t point_filter_num;  /* 2   config/livox.yaml:40 */
+  double blind;              /* 0.1 config/livox.yaml:9 (compared squared, pointcloud_preprocess.cc:70-72) */
+  float leaf_size;           /* filter_size_surf 0.5  config/livox.yaml:38; 0 = no down-sampling */
+  int32_t reserved;
+} pcm_lio_frame_params;
+int pcm_lio_frame_begin(pcm_ctx *ctx, const void *custom_points, size_t n, int memory, const pcm_lio_frame_params *params, const pcm_imu_pose *poses, int num_poses,
+                        const pcm_lio_state *end_state, size_t *n_scan);
+int pcm_lio_frame_end(pcm_ctx *ctx, const pcm_lio_state *state, float filter_size_map, int ekf_inited, size_t *num_added);
+/* the current source scan, x y z per point in its stored order (tests: the scan pcm_lio_frame_begin produced); out may be NULL */
+int pcm_get_source(pcm_ctx *ctx, float *out_xyz, size_t capacity_points, size_t *n);
 
 /* Batch of independent registration objects on one device (BASELINE config 3:
  * independent scan/submap pairs): all GN/LM loops advance in lock-step kernel

@@ -14,7 +14,7 @@ SYMBOLS = [
     "pcm_get_config", "pcm_set_config", "pcm_set_stream", "pcm_set_target", "pcm_set_source",
     "pcm_swap_source_and_target", "pcm_clear_source", "pcm_clear_target", "pcm_align",
     "pcm_linearize", "pcm_compute_error", "pcm_get_planes", "pcm_get_lio_members", "pcm_obs_model", "pcm_target_insert", "pcm_map_incremental", "pcm_get_target", "pcm_get_covariances", "pcm_set_covariances", "pcm_ndt_derivatives", "pcm_ndt_score", "pcm_fitness_score", "pcm_undistort", "pcm_voxel_downsample", "pcm_livox_filter", "pcm_gicp_bfgs_set_correspondences", "pcm_gicp_bfgs_fdf", "pcm_gicp_bfgs_update_correspondences", "pcm_gicp_bfgs_get_correspondences", "pcm_align_batch", "pcm_set_profiling", "pcm_debug_phase_cycles",
-    "pcm_get_stats", "pcm_reset_stats",
+    "pcm_get_stats", "pcm_reset_stats", "pcm_lio_frame_begin", "pcm_lio_frame_end", "pcm_get_source",
 ]
 
 PCM_ABI_VERSION = 3   # include/pcm_amd.h
@@ -66,12 +66,17 @@ class PcmObsResult(C.Structure):
     _fields_ = [("HTH", C.c_double * 144), ("HTh", C.c_double * 12), ("sum_h2", C.c_double), ("n_eff", C.c_int32), ("valid", C.c_int32)]
 
 
+class PcmLioFrameParams(C.Structure):
+    _fields_ = [("num_scans", C.c_int32), ("point_filter_num", C.c_int32), ("blind", C.c_double), ("leaf_size", C.c_float), ("reserved", C.c_int32)]
+
+
 class PcmStats(C.Structure):
     _fields_ = [("linearize_launches", C.c_uint64), ("point_passes", C.c_uint64),
                 ("candidates", C.c_uint64), ("slots_probed", C.c_uint64), ("linearize_ms", C.c_double),
                 ("target_voxels", C.c_uint64), ("target_slots", C.c_uint64), ("tiles", C.c_uint64),
                 ("tiles_lds_grid", C.c_uint64), ("tiles_lds_points", C.c_uint64), ("residual_ms", C.c_double),
-                ("timed_launches", C.c_uint64), ("timed_pair_slots", C.c_uint64), ("launched_pair_slots", C.c_uint64)]
+                ("timed_launches", C.c_uint64), ("timed_pair_slots", C.c_uint64), ("launched_pair_slots", C.c_uint64),
+                ("lru_batch_hazards", C.c_uint64)]
 
 
 def library_path() -> str:
@@ -150,5 +155,8 @@ def load_library():
     L.pcm_set_profiling.argtypes = [vp, i32]
     L.pcm_debug_phase_cycles.argtypes = [vp, vp]
     L.pcm_get_stats.argtypes = [vp, C.POINTER(PcmStats)]
+    L.pcm_lio_frame_begin.argtypes = [vp, vp, sz, C.c_int, C.POINTER(PcmLioFrameParams), vp, C.c_int, C.POINTER(PcmLioState), C.POINTER(sz)]
+    L.pcm_lio_frame_end.argtypes = [vp, C.POINTER(PcmLioState), C.c_float, i32, C.POINTER(sz)]
+    L.pcm_get_source.argtypes = [vp, vp, sz, C.POINTER(sz)]
     _LIB = L
     return L

@@ -49,7 +49,6 @@ constexpr int kCCapBricks = 64;
 constexpr int kCCapJobs = 48;        // queued 3- and 4-neighbour (double-precision) plane fits per round of the queue
 constexpr int kCBatch = 4;           // candidates of one cell fetched together
 constexpr uint32_t kCMaxCount = 255u;   // points per voxel a cell can say; a tile that sees more searches the global structures
-constexpr uint16_t kCNoCell = 0xffffu;
 // staging tables (brick origin, first map point, offset in s_pts) until the points are staged; afterwards the same bytes queue the
 // double-precision fits
 constexpr int kCTblBorg = 0, kCTblBps = kCCapBricks * 8, kCTblBoff = kCTblBps + kCCapBricks * 4, kCTblBytes = kCTblBoff + (kCCapBricks + 1) * 4;

@@ -231,7 +231,11 @@ int prepare(pcm_ctx* c) {
     uint32_t n_log = (uint32_t)c->tgt.n;
     // the sliding-map capacity belongs to the iVox of the P2PLANE / LIO path; fast_gicp keeps every target point
     const uint32_t capacity = c->cfg.model == PCM_MODEL_P2PLANE ? (uint32_t)std::max(0, c->cfg.map_capacity) : 0u;
-    int rc = build_target_map(c->stream, c->tgt.d_pts, &n_log, c->cfg.voxel_resolution, mode, gauss, capacity, &c->map, &c->err, gicp);
+    // a map whose log only grew since its last build (pcm_target_insert / pcm_map_incremental) is updated: the new points are merged
+    // into the sorted index it kept (voxel_hash.hip); anything else is built from scratch
+    uint32_t hazards = 0;
+    int rc = build_target_map(c->stream, c->tgt.d_pts, &n_log, c->cfg.voxel_resolution, mode, gauss, capacity, &c->map, &c->err, gicp, c->map.index_n, &hazards);
+    c->stats.lru_batch_hazards += hazards;
     c->tgt.n = n_log;   // LRU eviction compacts the point log
     if (rc != PCM_OK) return rc;
     c->stats.target_voxels = c->map.num_voxels;
@@ -1079,6 +1083,7 @@ int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   int rc = set_cloud(c, &c->tgt, points, n, stride_bytes, memory, tag, false);
   c->user_cov[1].clear();   // target_covs_.clear()  fast_gicp_impl.hpp:89
   c->map.valid = false;
+  c->map.index_n = 0;   // another log: the sorted index of the old one is of no use
   c->next_seq = (uint32_t)n;
   c->lio_planes_valid = false;
   return rc;
@@ -1124,6 +1129,7 @@ int pcm_swap_source_and_target(pcm_ctx* c) {
   std::swap(c->user_cov[0], c->user_cov[1]);   // source_covs_.swap(target_covs_)  fast_gicp_impl.hpp:55
   c->map.valid = false;
   c->srcmap.valid = false;
+  c->map.index_n = 0; c->srcmap.index_n = 0;
   c->src_sorted = false;
   return PCM_OK;
 }
@@ -1136,7 +1142,7 @@ int pcm_clear_source(pcm_ctx* c) {
 
 int pcm_clear_target(pcm_ctx* c) {
   CHECK_CTX(c);
-  c->tgt.n = 0; c->tgt.tag = 0; c->map.valid = false;
+  c->tgt.n = 0; c->tgt.tag = 0; c->map.valid = false; c->map.index_n = 0;
   return PCM_OK;
 }
 
@@ -1749,6 +1755,93 @@ int pcm_map_incremental(pcm_ctx* c, const pcm_lio_state* s, float filter_size_ma
   c->tgt.tag = 0;
   if (added) c->map.valid = false;
   if (num_added) *num_added = added;
+  return PCM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// One LiDAR frame of LaserMapping::Run on device buffers (jueying_lio/src/laser_mapping.cc:323-347 front end, :525-583 back end).
+// ---------------------------------------------------------------------------
+int pcm_lio_frame_begin(pcm_ctx* c, const void* custom_points, size_t n, int memory, const pcm_lio_frame_params* prm, const pcm_imu_pose* poses, int npose,
+                        const pcm_lio_state* end_state, size_t* n_scan) {
+  CHECK_CTX(c);
+  if ((!custom_points && n) || !prm || !n_scan || (npose >= 2 && (!poses || !end_state))) return PCM_ERR_INVALID_ARGUMENT;
+  if (n > 0xffffffffull) { c->err = "too many points"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (!(prm->leaf_size >= 0.f)) { c->err = "leaf_size must be >= 0"; return PCM_ERR_INVALID_ARGUMENT; }
+  *n_scan = 0;
+  if (n == 0) { c->err = "empty frame"; return PCM_ERR_NO_INPUT; }
+  HIPCK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  // frame arena: [raw message | filtered records | down-sampled records | IMU poses | scratch of the operators]; grow-only, so the
+  // steady state makes no allocation.  The raw message is the only host -> device copy of the frame.
+  const size_t o_raw = 0, o_flt = o_raw + up(n * 20), o_ds = o_flt + up(n * 48), o_pose = o_ds + up(n * 48);
+  const size_t o_scr = o_pose + up(sizeof(pcm_imu_pose) * (size_t)std::max(npose, 1));
+  const size_t need = o_scr + std::max(livox_filter_scratch_bytes(n), voxel_downsample_scratch_bytes(n));
+  if (c->pre_arena_cap < need) {
+    if (c->pre_arena) hipFree(c->pre_arena);
+    c->pre_arena = nullptr; c->pre_arena_cap = 0;
+    HIPCK(c, hipMalloc(&c->pre_arena, need + need / 4));
+    c->pre_arena_cap = need + need / 4;
+  }
+  char* A = c->pre_arena;
+  const void* d_raw = custom_points;
+  if (memory == PCM_MEM_HOST) {
+    HIPCK(c, hipMemcpyAsync(A + o_raw, custom_points, n * 20, hipMemcpyHostToDevice, st));
+    d_raw = A + o_raw;
+  }
+  // 1. PointCloudPreprocess::AviaHandler  (pointcloud_preprocess.cc:44-88)
+  size_t n_flt = 0;
+  int rc = livox_filter_device(st, d_raw, n, prm->num_scans, prm->point_filter_num, prm->blind, A + o_flt, &n_flt, A + o_scr, &c->err);
+  if (rc != PCM_OK) return rc;
+  if (n_flt == 0) { c->err = "no point of the frame passed the driver-message filter"; return PCM_ERR_NO_INPUT; }
+  // 2. ImuProcess::UndistortPcl backward loop  (imu_processing.hpp:245-285): in place on the filtered records (time stamp = curvature).
+  //    The reference sorts the scan by time first (:177-178); a Livox message is time-ordered, and the compensation of a point
+  //    depends on its own stamp only, so the message order is kept.
+  if (npose >= 2) {
+    LioStateD s;
+    for (int a = 0; a < 4; a++) { s.rot[a] = end_state->rot[a]; s.off_R[a] = end_state->off_R[a]; }
+    for (int a = 0; a < 3; a++) { s.pos[a] = end_state->pos[a]; s.off_T[a] = end_state->off_T[a]; }
+    HIPCK(c, hipMemcpyAsync(A + o_pose, poses, sizeof(pcm_imu_pose) * (size_t)npose, hipMemcpyHostToDevice, st));
+    rc = undistort_device(st, A + o_flt, n_flt, 48, 36, reinterpret_cast<const pcm_imu_pose*>(A + o_pose), npose, s, &c->err);   // PointXYZINormal::curvature: byte 36
+    if (rc != PCM_OK) return rc;
+  }
+  // 3. voxel_scan_.filter()  (laser_mapping.cc:323-328); leaf 0 = no down-sampling
+  const char* d_scan = A + o_flt;
+  size_t n_ds = n_flt;
+  if (prm->leaf_size > 0.f) {
+    rc = voxel_downsample_device(st, A + o_flt, n_flt, 48, prm->leaf_size, reinterpret_cast<float*>(A + o_ds), &n_ds, A + o_scr, &c->err);
+    if (rc != PCM_OK) return rc;
+    d_scan = A + o_ds;
+  }
+  if (n_ds == 0) { c->err = "empty scan after down-sampling"; return PCM_ERR_NO_INPUT; }
+  // 4. the down-sampled scan (scan_down_body_) becomes the source of this object: device -> device, no host copy
+  if (c->cfg.flags & PCM_FLAG_LIO_REFERENCE_SEMANTICS) {   // one resize of residuals_ / point_selected_surf_ per frame  laser_mapping.cc:335-339
+    rc = lio_members_resize(c, n_ds);
+    if (rc != PCM_OK) return rc;
+  }
+  rc = set_cloud(c, &c->src, d_scan, n_ds, 48, PCM_MEM_DEVICE, 0, false);
+  if (rc != PCM_OK) return rc;
+  c->src_sorted = false;
+  c->lio_planes_valid = false;
+  c->srcmap.valid = false;
+  c->src_cov_valid = false;
+  c->user_cov[0].clear();
+  *n_scan = n_ds;
+  return PCM_OK;
+}
+
+int pcm_lio_frame_end(pcm_ctx* c, const pcm_lio_state* s, float filter_size_map, int ekf_inited, size_t* num_added) { return pcm_map_incremental(c, s, filter_size_map, ekf_inited, num_added); }
+
+int pcm_get_source(pcm_ctx* c, float* out_xyz, size_t capacity_points, size_t* n) {
+  CHECK_CTX(c);
+  if (!n) return PCM_ERR_INVALID_ARGUMENT;
+  *n = c->src.n;
+  if (!out_xyz) return PCM_OK;
+  if (capacity_points < c->src.n) { c->err = "pcm_get_source: buffer too small"; return PCM_ERR_INVALID_ARGUMENT; }
+  std::vector<float4> tmp(c->src.n);
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipMemcpy(tmp.data(), c->src.d_pts, sizeof(float4) * c->src.n, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < c->src.n; i++) { out_xyz[3 * i] = tmp[i].x; out_xyz[3 * i + 1] = tmp[i].y; out_xyz[3 * i + 2] = tmp[i].z; }
   return PCM_OK;
 }
 

@@ -36,6 +36,13 @@ struct TargetMap {   // layout: pcm_device.h
   float4* pts = nullptr;
   GaussVoxel* gvox = nullptr;   // NDT models
   uint32_t* order = nullptr;    // input index of every map point (kept on request: GICP covariances are reported in input order)
+  // the sorted index of the point log the tables were built from (key, log position), kept for the next batch of a sliding map
+  // (voxel_hash.hip: merged, not re-sorted), and its double buffer
+  uint64_t *keys_s = nullptr, *keys_t = nullptr;
+  uint32_t *idx_s = nullptr, *idx_t = nullptr;
+  size_t keys_cap = 0, keys_t_cap = 0, idx_cap = 0, idx_t_cap = 0, vox_cap = 0, pts_cap = 0;
+  uint32_t bricks_cap = 0;      // allocated slots of bricks / bmask / bpref (cap <= bricks_cap is the table in use)
+  uint32_t index_n = 0;         // log points keys_s / idx_s cover (0: no usable index)
   uint32_t cap = 0, num_voxels = 0, num_bricks = 0, num_points = 0;
   uint32_t max_voxel_points = 0;   // most points in one voxel
   float res = 0.f, inv_res = 0.f;
@@ -49,14 +56,20 @@ struct TargetMap {   // layout: pcm_device.h
     if (pts) hipFree(pts);
     if (gvox) hipFree(gvox);
     if (order) hipFree(order);
-    gvox = nullptr; order = nullptr;
+    if (keys_s) hipFree(keys_s);
+    if (keys_t) hipFree(keys_t);
+    if (idx_s) hipFree(idx_s);
+    if (idx_t) hipFree(idx_t);
+    gvox = nullptr; order = nullptr; keys_s = keys_t = nullptr; idx_s = idx_t = nullptr;
     bricks = nullptr; bmask = nullptr; bpref = nullptr; vox_start = nullptr; pts = nullptr;
+    keys_cap = keys_t_cap = idx_cap = idx_t_cap = vox_cap = pts_cap = 0; bricks_cap = 0; index_n = 0;
     cap = num_voxels = num_bricks = num_points = 0; max_voxel_points = 0; valid = false;
   }
 };
 
+// n_indexed > 0: the first n_indexed points of the log are what map->keys_s / idx_s index; only the points behind them are new
 int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
-                     std::string* err, bool keep_order = false);
+                     std::string* err, bool keep_order = false, uint32_t n_indexed = 0, uint32_t* lru_hazards = nullptr);
 int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, uint32_t seq0, float4* d_out, std::string* err);
 // batched scan re-ordering (voxel_hash.hip)
 struct SortJob {

@@ -239,18 +239,118 @@ __global__ void k_gauss_voxels(const float4* __restrict__ pts, const uint32_t* _
   out[v] = g;
 }
 
-// Build the voxel hash of `cloud` into `map`.  One host sync (voxel / brick counts -> array sizes).
+// ---------------------------------------------------------------------------
+// Sliding map: the sorted index of the point log is PERSISTENT (TargetMap::keys_s / idx_s), a batch of appended points is
+// merged into it instead of re-sorting the whole log, the tables are rebuilt from the merged index in capacity-managed arrays
+// (no allocation per frame), and an LRU eviction compacts log and index in place instead of building everything a second time.
+//   IVox::AddPoints + LRU cache   /root/reference/src/jueying_lio/include/ivox3d/ivox3d.h:256-281
+// Policy of the linear-probed brick table under insert + evict: the table is rebuilt from the merged index every
+// batch (one slot per occupied brick, load <= 0.25) -- bricks never need a tombstone because no slot outlives a batch; what is
+// incremental is everything that is expensive: the 63-bit sort of the log (replaced by a sort of the batch + two merge passes)
+// and the second build an eviction used to trigger.  The result is identical to a full build of the same log, structure for structure.
+// ---------------------------------------------------------------------------
+__global__ void k_point_keys_at(const float4* __restrict__ pts, uint32_t first, uint32_t m, float res, float inv_res, int mode, uint64_t* __restrict__ keys,
+                                uint32_t* __restrict__ idx, int* __restrict__ oor) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const float4 p = pts[first + j];
+  int c[3] = {voxel_coord(p.x, res, inv_res, mode), voxel_coord(p.y, res, inv_res, mode), voxel_coord(p.z, res, inv_res, mode)};
+  bool bad = !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z));
+  for (int a = 0; a < 3; a++) {
+    if (c[a] < -kCoordBias + 16 || c[a] > kCoordBias - 17) { bad = true; c[a] = 0; }
+  }
+  if (bad) atomicOr(oor, 1);
+  keys[j] = point_key(c[0], c[1], c[2]);
+  idx[j] = first + j;
+}
+
+// stable merge of the sorted batch (keys_b, m) into the sorted index (keys_a, n): an old entry goes behind the batch entries with
+// a SMALLER key, a batch entry behind every old entry with a smaller OR EQUAL key (a voxel keeps its points in insertion order)
+__global__ void k_merge_old(const uint64_t* __restrict__ keys_a, const uint32_t* __restrict__ idx_a, uint32_t n, const uint64_t* __restrict__ keys_b, uint32_t m,
+                            uint64_t* __restrict__ keys_o, uint32_t* __restrict__ idx_o) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys_a[i];
+  uint32_t lo = 0, hi = m;   // lower_bound: first batch key >= k
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys_b[mid] < k) lo = mid + 1; else hi = mid; }
+  keys_o[i + lo] = k;
+  idx_o[i + lo] = idx_a[i];
+}
+__global__ void k_merge_new(const uint64_t* __restrict__ keys_a, uint32_t n, const uint64_t* __restrict__ keys_b, const uint32_t* __restrict__ idx_b, uint32_t m,
+                            uint64_t* __restrict__ keys_o, uint32_t* __restrict__ idx_o) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const uint64_t k = keys_b[j];
+  uint32_t lo = 0, hi = n;   // upper_bound: first old key > k
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys_a[mid] <= k) lo = mid + 1; else hi = mid; }
+  keys_o[j + lo] = k;
+  idx_o[j + lo] = idx_b[j];
+}
+
+// eviction: survivors of the sorted index, re-pointed at the compacted log
+__global__ void k_compact_index(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ alive_log, const uint32_t* __restrict__ pos_log,
+                                const uint32_t* __restrict__ pos_idx, uint32_t n, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t l = idx_in[i];
+  if (!alive_log[l]) return;
+  keys_out[pos_idx[i]] = keys_in[i];
+  idx_out[pos_idx[i]] = pos_log[l];
+}
+__global__ void k_alive_sorted(const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ alive_log, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = alive_log[idx_s[i]];
+}
+// A voxel that this batch touched, that existed before the batch and whose last touch BEFORE the batch is older than the eviction
+// cut-off: the reference's sequential list (ivox3d.h:256-281) may have dropped it before the batch reached it and re-created it
+// with the batch's points alone; the batch rule here keeps it whole.  Counted, reported (pcm_stats.lru_batch_hazards), not hidden.
+__global__ void k_lru_hazards(const float4* __restrict__ log, const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vox_first, uint32_t nvox, uint32_t n,
+                              uint32_t seq0, uint32_t cutoff, unsigned int* __restrict__ out) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t p0 = vox_first[v], p1 = v + 1 < nvox ? vox_first[v + 1] : n;
+  if (__float_as_uint(log[idx_s[p1 - 1]].w) < seq0) return;          // not touched by this batch
+  uint32_t k = p1 - 1;
+  while (k > p0 && __float_as_uint(log[idx_s[k]].w) >= seq0) k--;     // a voxel's points are in insertion order
+  const uint32_t before = __float_as_uint(log[idx_s[k]].w);
+  if (before < seq0 && before < cutoff) atomicAdd(out, 1u);
+}
+__global__ void k_voxel_firsts(const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vrank, uint32_t n, uint32_t* __restrict__ vox_first) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && vflag[i]) vox_first[vrank[i]] = i;
+}
+
+template <typename T>
+static int grow(T** p, size_t* cap, size_t need, size_t keep_elems, hipStream_t stream, std::string* err, const char* what) {
+  if (need <= *cap) return PCM_OK;
+  const size_t nc = need + need / 4 + 1024;
+  T* q = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&q), sizeof(T) * nc) != hipSuccess) { *err = std::string("hipMalloc(") + what + ")"; return PCM_ERR_HIP; }
+  if (*p && keep_elems) {
+    if (hipMemcpyAsync(q, *p, sizeof(T) * keep_elems, hipMemcpyDeviceToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { hipFree(q); *err = std::string("copy(") + what + ")"; return PCM_ERR_HIP; }
+  } else if (*p) {
+    (void)hipStreamSynchronize(stream);   // queued kernels may still read the old array
+  }
+  if (*p) hipFree(*p);
+  *p = q; *cap = nc;
+  return PCM_OK;
+}
+
+// Build the voxel hash of the point log `d_pts` into `map`, or -- `n_indexed` > 0: the first n_indexed log points are what
+// map->keys_s / idx_s index -- merge the points appended since.  Host syncs: voxel / brick counts (array sizes), once more after
+// an eviction.
 int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
-                     std::string* err, bool keep_order) {
-  map->release();
+                     std::string* err, bool keep_order, uint32_t n_indexed, uint32_t* lru_hazards) {
   uint32_t n = *n_inout;
-  if (n == 0) { *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
-  uint64_t *keys = nullptr, *keys_s = nullptr;
-  uint32_t *idx = nullptr, *idx_s = nullptr, *vflag = nullptr, *vrank = nullptr;
-  int* d_flags = nullptr;  // [0] out-of-range flag, [1] brick count, [2] most points in one voxel
+  if (n == 0) { map->release(); *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
+  const bool incremental = n_indexed > 0 && n_indexed <= n && map->keys_s && map->idx_s && map->index_n == n_indexed && map->res == res && map->coord_mode == coord_mode && !want_gauss && !keep_order;
+  uint64_t *keys_b = nullptr, *keys_bs = nullptr;
+  uint32_t *idx_b = nullptr, *idx_bs = nullptr, *vflag = nullptr, *vrank = nullptr;
+  int* d_flags = nullptr;  // [0] out-of-range flag, [1] brick count, [2] most points in one voxel, [3] LRU hazards
   void *tmp = nullptr, *tmp2 = nullptr;
   size_t tmp_bytes = 0, tmp2_bytes = 0;
   int rc = PCM_OK;
+  uint32_t hazards = 0;
   // ivox3d.h:67  inv_resolution_ = 1.0 / resolution_ (float);  pcl::VoxelGrid: inverse_leaf_size_ = 1 / leaf_size_ in float
   const float inv_res = coord_mode == COORD_FLOOR_MUL ? 1.0f / res : (float)(1.0 / res);
 #define CK(x)                                                                    \
@@ -258,43 +358,76 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     hipError_t e_ = (x);                                                         \
     if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc = PCM_ERR_HIP; goto done; } \
   } while (0)
-  CK(hipMallocAsync(&keys, sizeof(uint64_t) * n, stream));
-  CK(hipMallocAsync(&keys_s, sizeof(uint64_t) * n, stream));
-  CK(hipMallocAsync(&idx, sizeof(uint32_t) * n, stream));
-  CK(hipMallocAsync(&idx_s, sizeof(uint32_t) * n, stream));
-  CK(hipMallocAsync(&vflag, sizeof(uint32_t) * n, stream));
-  CK(hipMallocAsync(&vrank, sizeof(uint32_t) * n, stream));
-  CK(hipMallocAsync(&d_flags, 3 * sizeof(int), stream));
-  CK(hipMemsetAsync(d_flags, 0, 3 * sizeof(int), stream));
-  k_point_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, n, res, inv_res, coord_mode, keys, idx, d_flags);
-  CK(hipGetLastError());
-  CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
-  CK(hipMallocAsync(&tmp, tmp_bytes, stream));
-  CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, idx, idx_s, n, 0, 63, stream));
-  k_head_flags<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, n, vflag, reinterpret_cast<unsigned int*>(d_flags + 1));
-  CK(hipGetLastError());
-  CK(rocprim::exclusive_scan(nullptr, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-  CK(hipMallocAsync(&tmp2, tmp2_bytes, stream));
-  CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+#define RC(x) do { rc = (x); if (rc != PCM_OK) goto done; } while (0)
+  map->valid = false;
+  CK(hipMallocAsync(&d_flags, 4 * sizeof(int), stream));
+  CK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), stream));
   {
-    int h_flags[2];
-    uint32_t h_last[2];
-    CK(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
-    CK(hipMemcpyAsync(&h_last[0], vrank + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    CK(hipMemcpyAsync(&h_last[1], vflag + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    CK(hipStreamSynchronize(stream));
-    if (h_flags[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
-    const uint32_t nvox = h_last[0] + h_last[1];
-    const uint32_t nbricks = (uint32_t)h_flags[1];
+    // ---- 1. the sorted index (key, log position) of all n log points in map->keys_s / idx_s ------------------------------
+    const uint32_t first = incremental ? n_indexed : 0u, m = n - first;
+    RC(grow(&map->keys_s, &map->keys_cap, n, incremental ? n_indexed : 0, stream, err, "keys_s"));
+    RC(grow(&map->idx_s, &map->idx_cap, n, incremental ? n_indexed : 0, stream, err, "idx_s"));
+    RC(grow(&map->keys_t, &map->keys_t_cap, n, 0, stream, err, "keys_t"));
+    RC(grow(&map->idx_t, &map->idx_t_cap, n, 0, stream, err, "idx_t"));
+    if (m > 0) {
+      CK(hipMallocAsync(&keys_b, sizeof(uint64_t) * m, stream));
+      CK(hipMallocAsync(&keys_bs, sizeof(uint64_t) * m, stream));
+      CK(hipMallocAsync(&idx_b, sizeof(uint32_t) * m, stream));
+      CK(hipMallocAsync(&idx_bs, sizeof(uint32_t) * m, stream));
+      k_point_keys_at<<<cdiv(m, 256), 256, 0, stream>>>(d_pts, first, m, res, inv_res, coord_mode, keys_b, idx_b, d_flags);
+      CK(hipGetLastError());
+      uint64_t* ks = incremental ? keys_bs : map->keys_s;   // a full build sorts straight into the persistent index
+      uint32_t* is = incremental ? idx_bs : map->idx_s;
+      CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_b, ks, idx_b, is, m, 0, 63, stream));
+      CK(hipMallocAsync(&tmp, tmp_bytes, stream));
+      CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_b, ks, idx_b, is, m, 0, 63, stream));
+      if (incremental) {
+        k_merge_old<<<cdiv(n_indexed, 256), 256, 0, stream>>>(map->keys_s, map->idx_s, n_indexed, keys_bs, m, map->keys_t, map->idx_t);
+        k_merge_new<<<cdiv(m, 256), 256, 0, stream>>>(map->keys_s, n_indexed, keys_bs, idx_bs, m, map->keys_t, map->idx_t);
+        CK(hipGetLastError());
+        std::swap(map->keys_s, map->keys_t); std::swap(map->keys_cap, map->keys_t_cap);
+        std::swap(map->idx_s, map->idx_t); std::swap(map->idx_cap, map->idx_t_cap);
+      }
+    }
+    map->index_n = 0;   // until this build is through
+    // ---- 2. voxel heads, ranks; counts to the host -----------------------------------------------------------------------
+    CK(hipMallocAsync(&vflag, sizeof(uint32_t) * n, stream));
+    CK(hipMallocAsync(&vrank, sizeof(uint32_t) * n, stream));
+    uint32_t nvox = 0, nbricks = 0;
+    auto heads = [&](uint32_t cnt) -> int {
+      CK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
+      k_head_flags<<<cdiv(cnt, 256), 256, 0, stream>>>(map->keys_s, cnt, vflag, reinterpret_cast<unsigned int*>(d_flags + 1));
+      CK(hipGetLastError());
+      if (!tmp2) {
+        CK(rocprim::exclusive_scan(nullptr, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+        CK(hipMallocAsync(&tmp2, tmp2_bytes, stream));
+      }
+      {
+        size_t tb = tmp2_bytes;
+        CK(rocprim::exclusive_scan(tmp2, tb, vflag, vrank, 0u, (size_t)cnt, rocprim::plus<uint32_t>(), stream));
+      }
+      int h_flags[2];
+      uint32_t h_last[2];
+      CK(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
+      CK(hipMemcpyAsync(&h_last[0], vrank + (cnt - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CK(hipMemcpyAsync(&h_last[1], vflag + (cnt - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CK(hipStreamSynchronize(stream));
+      if (h_flags[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
+      nvox = h_last[0] + h_last[1];
+      nbricks = (uint32_t)h_flags[1];
+      return PCM_OK;
+    done:
+      return rc;
+    };
+    RC(heads(n));
     if (capacity_voxels > 1 && nvox > capacity_voxels - 1) {
-      // ---- LRU eviction: keep the (capacity - 1) most recently touched voxels, compact the log, rebuild ----
+      // ---- 3. LRU eviction: keep the (capacity - 1) most recently touched voxels; log and index are compacted in place ------
       const uint32_t keep = capacity_voxels - 1;
-      uint32_t *vlast = nullptr, *vsorted = nullptr, *alive = nullptr, *pos = nullptr;
+      uint32_t *vlast = nullptr, *vsorted = nullptr, *alive = nullptr, *pos = nullptr, *alive_s = nullptr, *pos_s = nullptr, *vfirst = nullptr;
       float4* tmp_log = nullptr;
-      void* tmp3 = nullptr;
+      void *tmp3 = nullptr, *tmp4 = nullptr;
       size_t tmp3_bytes = 0, tmp4_bytes = 0;
-      void* tmp4 = nullptr;
-      uint32_t cutoff = 0, h_tail[2] = {0, 0};
+      uint32_t cutoff = 0, h_tail[2] = {0, 0}, h_haz = 0;
       int rc2 = PCM_OK;
 #define CK2(x)                                                                   \
   do {                                                                           \
@@ -303,68 +436,97 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   } while (0)
       CK2(hipMallocAsync(&vlast, sizeof(uint32_t) * nvox, stream));
       CK2(hipMallocAsync(&vsorted, sizeof(uint32_t) * nvox, stream));
+      CK2(hipMallocAsync(&vfirst, sizeof(uint32_t) * nvox, stream));
       CK2(hipMallocAsync(&alive, sizeof(uint32_t) * n, stream));
       CK2(hipMallocAsync(&pos, sizeof(uint32_t) * n, stream));
+      CK2(hipMallocAsync(&alive_s, sizeof(uint32_t) * n, stream));
+      CK2(hipMallocAsync(&pos_s, sizeof(uint32_t) * n, stream));
       CK2(hipMallocAsync(&tmp_log, sizeof(float4) * n, stream));
       CK2(hipMemsetAsync(vlast, 0, sizeof(uint32_t) * nvox, stream));
-      k_voxel_last<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, vflag, vrank, n, vlast);
+      k_voxel_last<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, map->idx_s, vflag, vrank, n, vlast);
       CK2(hipGetLastError());
       CK2(rocprim::radix_sort_keys(nullptr, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
       CK2(hipMallocAsync(&tmp3, tmp3_bytes, stream));
       CK2(rocprim::radix_sort_keys(tmp3, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
       CK2(hipMemcpyAsync(&cutoff, vsorted + (nvox - keep), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       CK2(hipStreamSynchronize(stream));
-      k_mark_alive<<<cdiv(n, 256), 256, 0, stream>>>(idx_s, vflag, vrank, vlast, cutoff, n, alive);
+      if (incremental) {   // the batch = the log points from n_indexed on; their sequence numbers start at the first one's
+        uint32_t seq0 = 0;
+        CK2(hipMemcpyAsync(&seq0, reinterpret_cast<const char*>(d_pts + n_indexed) + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        CK2(hipStreamSynchronize(stream));
+        k_voxel_firsts<<<cdiv(n, 256), 256, 0, stream>>>(vflag, vrank, n, vfirst);
+        k_lru_hazards<<<cdiv(nvox, 256), 256, 0, stream>>>(d_pts, map->idx_s, vfirst, nvox, n, seq0, cutoff, reinterpret_cast<unsigned int*>(d_flags + 3));
+        CK2(hipGetLastError());
+      }
+      k_mark_alive<<<cdiv(n, 256), 256, 0, stream>>>(map->idx_s, vflag, vrank, vlast, cutoff, n, alive);
       CK2(hipGetLastError());
       CK2(rocprim::exclusive_scan(nullptr, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
       CK2(hipMallocAsync(&tmp4, tmp4_bytes, stream));
-      CK2(rocprim::exclusive_scan(tmp4, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
+      { size_t tb = tmp4_bytes; CK2(rocprim::exclusive_scan(tmp4, tb, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream)); }
+      k_alive_sorted<<<cdiv(n, 256), 256, 0, stream>>>(map->idx_s, alive, n, alive_s);
+      { size_t tb = tmp4_bytes; CK2(rocprim::exclusive_scan(tmp4, tb, alive_s, pos_s, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream)); }
       k_compact_log<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, alive, pos, n, tmp_log);
+      k_compact_index<<<cdiv(n, 256), 256, 0, stream>>>(map->keys_s, map->idx_s, alive, pos, pos_s, n, map->keys_t, map->idx_t);
       CK2(hipGetLastError());
       CK2(hipMemcpyAsync(&h_tail[0], pos + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       CK2(hipMemcpyAsync(&h_tail[1], alive + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CK2(hipMemcpyAsync(&h_haz, d_flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       CK2(hipStreamSynchronize(stream));
-      CK2(hipMemcpyAsync(d_pts, tmp_log, sizeof(float4) * (size_t)(h_tail[0] + h_tail[1]), hipMemcpyDeviceToDevice, stream));
-      CK2(hipStreamSynchronize(stream));
-      *n_inout = h_tail[0] + h_tail[1];
+      n = h_tail[0] + h_tail[1];
+      hazards = h_haz;
+      CK2(hipMemcpyAsync(d_pts, tmp_log, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+      std::swap(map->keys_s, map->keys_t); std::swap(map->keys_cap, map->keys_t_cap);
+      std::swap(map->idx_s, map->idx_t); std::swap(map->idx_cap, map->idx_t_cap);
+      *n_inout = n;
     evict_done:
-      sfree(stream, vlast); sfree(stream, vsorted); sfree(stream, alive); sfree(stream, pos); sfree(stream, tmp_log); sfree(stream, tmp3); sfree(stream, tmp4);
+      sfree(stream, vlast); sfree(stream, vsorted); sfree(stream, vfirst); sfree(stream, alive); sfree(stream, pos); sfree(stream, alive_s); sfree(stream, pos_s);
+      sfree(stream, tmp_log); sfree(stream, tmp3); sfree(stream, tmp4);
 #undef CK2
-      sfree(stream, keys); sfree(stream, keys_s); sfree(stream, idx); sfree(stream, idx_s); sfree(stream, vflag); sfree(stream, vrank); sfree(stream, d_flags); sfree(stream, tmp); sfree(stream, tmp2);
-      if (rc2 != PCM_OK) return rc2;
-      return build_target_map(stream, d_pts, n_inout, res, coord_mode, want_gauss, 0u, map, err, keep_order);   // now within capacity
+      if (rc2 != PCM_OK) { rc = rc2; goto done; }
+      RC(heads(n));   // the survivors' voxel heads and ranks
     }
+    // ---- 4. tables from the sorted index (capacity-managed arrays: a sliding map allocates nothing in the steady state) ----
     uint32_t cap = 1024;
     while (cap < 4ull * nbricks) cap <<= 1;
     if (cap > kMaxBrickSlots) { *err = "too many occupied bricks"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
-    CK(hipMalloc(&map->bricks, sizeof(BrickSlot) * (size_t)cap));
-    CK(hipMalloc(&map->bmask, sizeof(uint32_t) * 16 * (size_t)cap));
-    CK(hipMalloc(&map->bpref, sizeof(uint16_t) * 16 * (size_t)cap));
-    CK(hipMalloc(&map->vox_start, sizeof(uint32_t) * ((size_t)nvox + 1)));
-    CK(hipMalloc(&map->pts, sizeof(float4) * (size_t)n));
+    if (cap > map->bricks_cap) {   // the table only grows; a smaller table uses the front of the allocation
+      (void)hipStreamSynchronize(stream);
+      if (map->bricks) hipFree(map->bricks);
+      if (map->bmask) hipFree(map->bmask);
+      if (map->bpref) hipFree(map->bpref);
+      map->bricks = nullptr; map->bmask = nullptr; map->bpref = nullptr; map->bricks_cap = 0;
+      CK(hipMalloc(&map->bricks, sizeof(BrickSlot) * (size_t)cap));
+      CK(hipMalloc(&map->bmask, sizeof(uint32_t) * 16 * (size_t)cap));
+      CK(hipMalloc(&map->bpref, sizeof(uint16_t) * 16 * (size_t)cap));
+      map->bricks_cap = cap;
+    }
+    RC(grow(&map->vox_start, &map->vox_cap, (size_t)nvox + 1, 0, stream, err, "vox_start"));
+    RC(grow(&map->pts, &map->pts_cap, (size_t)n, 0, stream, err, "pts"));
     CK(hipMemsetAsync(map->bricks, 0xFF, sizeof(BrickSlot) * (size_t)cap, stream));
     CK(hipMemsetAsync(map->bmask, 0, sizeof(uint32_t) * 16 * (size_t)cap, stream));
     CK(hipMemsetAsync(map->bpref, 0, sizeof(uint16_t) * 16 * (size_t)cap, stream));
-    k_insert_bricks<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, vrank, n, map->bricks, cap - 1);
+    k_insert_bricks<<<cdiv(n, 256), 256, 0, stream>>>(map->keys_s, vrank, n, map->bricks, cap - 1);
     CK(hipGetLastError());
-    k_fill_voxels<<<cdiv(n, 256), 256, 0, stream>>>(keys_s, vflag, vrank, n, nvox, map->vox_start, map->bricks, map->bmask, cap - 1);
+    k_fill_voxels<<<cdiv(n, 256), 256, 0, stream>>>(map->keys_s, vflag, vrank, n, nvox, map->vox_start, map->bricks, map->bmask, cap - 1);
     CK(hipGetLastError());
     k_finalize_bricks<<<cdiv(cap, 256), 256, 0, stream>>>(map->bricks, map->bmask, map->bpref, map->vox_start, cap);
     CK(hipGetLastError());
-    k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, idx_s, keys_s, vrank, map->vox_start, n, map->pts);
+    k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, map->idx_s, map->keys_s, vrank, map->vox_start, n, map->pts);
     CK(hipGetLastError());
     k_max_voxel_points<<<cdiv(nvox, 256), 256, 0, stream>>>(map->vox_start, nvox, reinterpret_cast<unsigned int*>(d_flags + 2));
     CK(hipGetLastError());
     CK(hipMemcpyAsync(&map->max_voxel_points, d_flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));   // complete at the synchronize below
+    if (map->gvox) { (void)hipStreamSynchronize(stream); hipFree(map->gvox); map->gvox = nullptr; }
+    if (map->order) { (void)hipStreamSynchronize(stream); hipFree(map->order); map->order = nullptr; }
     if (want_gauss) {
       CK(hipMalloc(&map->gvox, sizeof(GaussVoxel) * ((size_t)nvox + 1)));
       k_gauss_voxels<<<cdiv(nvox, 128), 128, 0, stream>>>(map->pts, map->vox_start, nvox, map->gvox);
       CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(stream));
-    if (keep_order) {   // a persistent copy (the scratch arrays come from the stream-ordered pool)
+    if (keep_order) {   // a persistent copy of the input index of every map point
       CK(hipMalloc(&map->order, sizeof(uint32_t) * (size_t)n));
-      CK(hipMemcpyAsync(map->order, idx_s, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+      CK(hipMemcpyAsync(map->order, map->idx_s, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
       CK(hipStreamSynchronize(stream));
     }
     map->cap = cap;
@@ -374,13 +536,16 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     map->res = res;
     map->inv_res = inv_res;
     map->coord_mode = coord_mode;
+    map->index_n = n;
     map->valid = true;
   }
 done:
-  sfree(stream, keys); sfree(stream, keys_s); sfree(stream, idx); sfree(stream, idx_s); sfree(stream, vflag); sfree(stream, vrank); sfree(stream, d_flags); sfree(stream, tmp); sfree(stream, tmp2);
+  sfree(stream, keys_b); sfree(stream, keys_bs); sfree(stream, idx_b); sfree(stream, idx_bs); sfree(stream, vflag); sfree(stream, vrank); sfree(stream, d_flags); sfree(stream, tmp); sfree(stream, tmp2);
+  if (lru_hazards) *lru_hazards = hazards;
   if (rc != PCM_OK) map->release();
   return rc;
 #undef CK
+#undef RC
 }
 
 // Re-order the scans of a whole batch along a Morton (Z-order) curve of their WORLD

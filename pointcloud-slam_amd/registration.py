@@ -192,6 +192,45 @@ class Registration:
         self._check(self._L.pcm_map_incremental(self._h, C.byref(st), C.c_float(filter_size_map), int(ekf_inited), C.byref(n)))
         return n.value
 
+    def lio_frame_begin(self, msg_points, poses=None, rot_xyzw=(0, 0, 0, 1.0), pos=(0, 0, 0), off_R_xyzw=(0, 0, 0, 1.0), off_T=(0, 0, 0),
+                        num_scans: int = 6, point_filter_num: int = 2, blind: float = 0.1, leaf_size: float = 0.5) -> int:
+        """Front end of one LaserMapping::Run frame on the device (pcm_lio_frame_begin): raw livox CustomPoint records (20-byte
+        structured array; host array or a CUDA uint8 tensor) -> driver-message filter -> motion compensation (poses: (K,22) Pose6D rows,
+        None = none) -> voxel-grid down-sampling -> source of this object.  Returns the number of scan points."""
+        mem, ptr, n = capi.MEM_HOST, None, 0
+        if hasattr(msg_points, "data_ptr"):
+            assert msg_points.is_cuda and msg_points.element_size() * msg_points.numel() % 20 == 0
+            mem, ptr, n = capi.MEM_DEVICE, msg_points.data_ptr(), msg_points.element_size() * msg_points.numel() // 20
+            self._keep_frame = msg_points
+        else:
+            a = np.ascontiguousarray(msg_points)
+            assert a.dtype.itemsize == 20
+            ptr, n = a.ctypes.data, len(a)
+            self._keep_frame = a
+        prm = capi.PcmLioFrameParams(int(num_scans), int(point_filter_num), float(blind), float(leaf_size), 0)
+        st = capi.PcmLioState()
+        st.rot[:] = list(map(float, rot_xyzw)); st.pos[:] = list(map(float, pos)); st.off_R[:] = list(map(float, off_R_xyzw)); st.off_T[:] = list(map(float, off_T))
+        pp, npose = None, 0
+        if poses is not None:
+            pa = np.ascontiguousarray(poses, dtype=np.float64)
+            assert pa.ndim == 2 and pa.shape[1] == 22
+            pp, npose = pa.ctypes.data, pa.shape[0]
+        m = C.c_size_t()
+        self._check(self._L.pcm_lio_frame_begin(self._h, C.c_void_p(ptr), C.c_size_t(n), mem, C.byref(prm), C.c_void_p(pp), int(npose), C.byref(st), C.byref(m)))
+        return m.value
+
+    def lio_frame_end(self, rot_xyzw, pos, off_R_xyzw, off_T, filter_size_map: float, ekf_inited: bool = True) -> int:
+        """Back end of the frame (pcm_lio_frame_end = MapIncremental with the updated state); returns the points inserted."""
+        return self.map_incremental(rot_xyzw, pos, off_R_xyzw, off_T, filter_size_map, ekf_inited)
+
+    def get_source(self) -> np.ndarray:
+        n = C.c_size_t()
+        self._check(self._L.pcm_get_source(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3), np.float32)
+        if n.value:
+            self._check(self._L.pcm_get_source(self._h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
     def ndt_derivatives(self, p, hessian="float"):
         """pclomp NDT: (score, gradient, Hessian) at the pose vector p = (x, y, z, roll, pitch, yaw)
         (computeDerivatives, ndt_omp_impl.hpp:168-267); hessian = "float" | None | "double" (computeHessian :498-559)."""

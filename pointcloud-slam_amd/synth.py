@@ -311,3 +311,20 @@ def corner_scene(n_scan: int, m_map: int, seed: int = 0, noise: float = 0.0, sca
     sm = np.ones((m_map, 4), np.float32); sm[:, :3] = m
     sc = np.ones((n_scan, 4), np.float32); sc[:, :3] = s_body
     return sc, sm, T
+
+
+LIVOX_POINT = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1"), ("pad", "u1")])
+
+
+def custom_msg(scan: np.ndarray, extras: dict, frame_ns: float = 99e6) -> np.ndarray:
+    """The points of a livox_ros_driver::CustomMsg (20-byte records, jueying_lio/thirdparty/livox_ros_driver/msg/CustomPoint.msg)
+    for a synthetic scan of livox_scan(): time-ordered offset_time in ns inside one frame, 6 lines, valid tags."""
+    n = len(scan)
+    a = np.zeros(n, LIVOX_POINT)
+    a["x"], a["y"], a["z"] = scan[:, 0], scan[:, 1], scan[:, 2]
+    t = np.asarray(extras["offset_time"], np.float64)
+    a["offset_time"] = np.clip((t - t.min()) / max(1e-12, float(t.max() - t.min())) * frame_ns, 0, frame_ns).astype(np.uint32)
+    a["reflectivity"] = extras["reflectivity"]
+    a["tag"] = extras["tag"]
+    a["line"] = np.asarray(extras["line"]) % 6
+    return a
