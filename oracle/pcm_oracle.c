@@ -679,8 +679,7 @@ static int step_lm(oracle *o, double x0[16], double delta[16]) {
       continue;
     }
     memcpy(x0, xi, sizeof(xi));
-    double c = 2 * rho - 1;
-    double f = 1 - c * c * c;
+    double f = 1 - pow(2 * rho - 1, 3);   /* std::pow(2 * rho - 1, 3): libm, as the reference calls it (lsq_registration_impl.hpp:166) */
     o->lm_lambda = o->lm_lambda * (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
     memcpy(o->final_hessian, H, sizeof(H));
     return 1;

@@ -183,6 +183,17 @@ PCM_HD void ldlt6_solve(const double* Ain, const double* rhs, double* x) {
   for (int i = 0; i < 6; i++) x[i] = y[i];
 }
 
+// x^3 rounded once: the reference writes std::pow(2 * rho - 1, 3) (lsq_registration_impl.hpp:166), and glibc's pow is correctly
+// rounded but for the rarest cases (0.52 ulp bound), whereas c * c * c rounds twice and is an ulp off every few hundred inputs --
+// enough to give lambda another last bit and, iterations later, another pose.  Exact square by fma, then the product with the
+// error term carried: the result is the correctly rounded cube unless the true value lies within ~1e-16 ulp of a rounding
+// boundary.  (The device's own pow() is a 1-2 ulp routine and is not used.)
+PCM_HD double cube_rn(double x) {
+  const double hi = x * x, lo = fma(x, x, -hi);            // x^2 = hi + lo exactly
+  const double r = hi * x, e = fma(hi, x, -r);             // hi * x = r + e exactly
+  return r + (e + lo * x);
+}
+
 // is_converged  (lsq_registration_impl.hpp:81-91)
 PCM_HD bool is_converged(const LsqParams& p, const double* delta) {
   double rmax = 0.0, tmax = 0.0;
@@ -270,8 +281,7 @@ PCM_HD void after_trial(PairState& s, const LsqParams& p, double yi) {
     return;
   }
   for (int i = 0; i < 16; i++) s.x0[i] = s.xi[i];
-  const double c = 2 * rho - 1;
-  const double f = 1 - c * c * c;
+  const double f = 1 - cube_rn(2 * rho - 1);   // std::pow(2 * rho - 1, 3)  lsq_registration_impl.hpp:166
   s.lambda = s.lambda * (f > 1.0 / 3.0 ? f : 1.0 / 3.0);
   for (int i = 0; i < 36; i++) s.final_hessian[i] = s.H[i];
   finish_outer(s, p, true);

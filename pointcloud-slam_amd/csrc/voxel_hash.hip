@@ -137,12 +137,15 @@ __global__ void k_gather_points(const float4* __restrict__ in, const uint32_t* _
 }
 
 // most points in one voxel (PCM_FLAG_REFERENCE_KNN_ORDER sizes a private array by it)
-__global__ void k_max_voxel_points(const uint32_t* __restrict__ vox_start, uint32_t nvox, unsigned int* __restrict__ out) {
-  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned int c = v < nvox ? vox_start[v + 1] - vox_start[v] : 0u;
+__global__ void __launch_bounds__(256) k_max_voxel_points(const uint32_t* __restrict__ vox_start, uint32_t nvox, unsigned int* __restrict__ out) {
+  unsigned int c = 0;
+  for (uint32_t v = blockIdx.x * 1024u + threadIdx.x; v < nvox && v < (blockIdx.x + 1u) * 1024u; v += 256u) c = max(c, vox_start[v + 1] - vox_start[v]);   // 4 voxels per lane
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) c = max(c, (unsigned int)__shfl_xor((int)c, off, 64));
-  if ((threadIdx.x & 63) == 0 && c) atomicMax(out, c);
+  __shared__ unsigned int s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { c = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])); if (c) atomicMax(out, c); }   // one atomic per 1024 voxels
 }
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -287,6 +290,25 @@ __global__ void k_merge_new(const uint64_t* __restrict__ keys_a, uint32_t n, con
   idx_o[j + lo] = idx_b[j];
 }
 
+// counters for the host in ONE record (read back with one copy into pinned memory): [4] voxels = rank + flag of the last point
+__global__ void k_count_voxels(const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vrank, uint32_t n, int* __restrict__ ctr) { ctr[4] = (int)(vrank[n - 1] + vflag[n - 1]); }
+__global__ void k_count_alive(const uint32_t* __restrict__ alive, const uint32_t* __restrict__ pos, uint32_t n, int* __restrict__ ctr) { ctr[5] = (int)(pos[n - 1] + alive[n - 1]); }
+// last touch of every voxel = sequence number of its last point (a voxel's points are in insertion order): no atomics
+__global__ void k_voxel_last_from_firsts(const float4* __restrict__ log, const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vox_first, uint32_t nvox, uint32_t n,
+                                         uint32_t* __restrict__ vlast) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const uint32_t p1 = v + 1 < nvox ? vox_first[v + 1] : n;
+  vlast[v] = __float_as_uint(log[idx_s[p1 - 1]].w);
+}
+// alive[log position] = its voxel's last touch is not older than the cut-off (read on the device: *cutoff)
+__global__ void k_mark_alive_dev(const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vrank, const uint32_t* __restrict__ vlast,
+                                 const uint32_t* __restrict__ cutoff, uint32_t n, uint32_t* __restrict__ alive) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  alive[idx_s[i]] = vlast[vrank[i] + vflag[i] - 1u] >= *cutoff ? 1u : 0u;
+}
+
 // eviction: survivors of the sorted index, re-pointed at the compacted log
 __global__ void k_compact_index(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, const uint32_t* __restrict__ alive_log, const uint32_t* __restrict__ pos_log,
                                 const uint32_t* __restrict__ pos_idx, uint32_t n, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
@@ -304,12 +326,13 @@ __global__ void k_alive_sorted(const uint32_t* __restrict__ idx_s, const uint32_
 // A voxel that this batch touched, that existed before the batch and whose last touch BEFORE the batch is older than the eviction
 // cut-off: the reference's sequential list (ivox3d.h:256-281) may have dropped it before the batch reached it and re-created it
 // with the batch's points alone; the batch rule here keeps it whole.  Counted, reported (pcm_stats.lru_batch_hazards), not hidden.
-__global__ void k_lru_hazards(const float4* __restrict__ log, const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vox_first, uint32_t nvox, uint32_t n,
-                              uint32_t seq0, uint32_t cutoff, unsigned int* __restrict__ out) {
+__global__ void k_lru_hazards(const float4* __restrict__ log, const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vox_first, const uint32_t* __restrict__ vlast,
+                              uint32_t nvox, uint32_t n, const float4* __restrict__ first_of_batch, const uint32_t* __restrict__ cutoff_p, unsigned int* __restrict__ out) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
+  const uint32_t seq0 = __float_as_uint(first_of_batch->w), cutoff = *cutoff_p;
+  if (vlast[v] < seq0) return;                                        // not touched by this batch
   const uint32_t p0 = vox_first[v], p1 = v + 1 < nvox ? vox_first[v + 1] : n;
-  if (__float_as_uint(log[idx_s[p1 - 1]].w) < seq0) return;          // not touched by this batch
   uint32_t k = p1 - 1;
   while (k > p0 && __float_as_uint(log[idx_s[k]].w) >= seq0) k--;     // a voxel's points are in insertion order
   const uint32_t before = __float_as_uint(log[idx_s[k]].w);
@@ -346,7 +369,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   const bool incremental = n_indexed > 0 && n_indexed <= n && map->keys_s && map->idx_s && map->index_n == n_indexed && map->res == res && map->coord_mode == coord_mode && !want_gauss && !keep_order;
   uint64_t *keys_b = nullptr, *keys_bs = nullptr;
   uint32_t *idx_b = nullptr, *idx_bs = nullptr, *vflag = nullptr, *vrank = nullptr;
-  int* d_flags = nullptr;  // [0] out-of-range flag, [1] brick count, [2] most points in one voxel, [3] LRU hazards
+  int* d_flags = nullptr;  // [0] out-of-range flag, [1] brick count, [2] most points in one voxel, [3] LRU hazards, [4] voxels, [5] log points alive
   void *tmp = nullptr, *tmp2 = nullptr;
   size_t tmp_bytes = 0, tmp2_bytes = 0;
   int rc = PCM_OK;
@@ -360,8 +383,9 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   } while (0)
 #define RC(x) do { rc = (x); if (rc != PCM_OK) goto done; } while (0)
   map->valid = false;
-  CK(hipMallocAsync(&d_flags, 4 * sizeof(int), stream));
-  CK(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), stream));
+  if (!map->h_ctr && hipHostMalloc(reinterpret_cast<void**>(&map->h_ctr), 8 * sizeof(int)) != hipSuccess) { *err = "hipHostMalloc(counters)"; return PCM_ERR_HIP; }
+  CK(hipMallocAsync(&d_flags, 8 * sizeof(int), stream));
+  CK(hipMemsetAsync(d_flags, 0, 8 * sizeof(int), stream));
   {
     // ---- 1. the sorted index (key, log position) of all n log points in map->keys_s / idx_s ------------------------------
     const uint32_t first = incremental ? n_indexed : 0u, m = n - first;
@@ -406,15 +430,12 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
         size_t tb = tmp2_bytes;
         CK(rocprim::exclusive_scan(tmp2, tb, vflag, vrank, 0u, (size_t)cnt, rocprim::plus<uint32_t>(), stream));
       }
-      int h_flags[2];
-      uint32_t h_last[2];
-      CK(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, stream));
-      CK(hipMemcpyAsync(&h_last[0], vrank + (cnt - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      CK(hipMemcpyAsync(&h_last[1], vflag + (cnt - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      k_count_voxels<<<1, 1, 0, stream>>>(vflag, vrank, cnt, d_flags);
+      CK(hipMemcpyAsync(map->h_ctr, d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));   // one copy into pinned memory
       CK(hipStreamSynchronize(stream));
-      if (h_flags[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
-      nvox = h_last[0] + h_last[1];
-      nbricks = (uint32_t)h_flags[1];
+      if (map->h_ctr[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
+      nvox = (uint32_t)map->h_ctr[4];
+      nbricks = (uint32_t)map->h_ctr[1];
       return PCM_OK;
     done:
       return rc;
@@ -427,7 +448,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       float4* tmp_log = nullptr;
       void *tmp3 = nullptr, *tmp4 = nullptr;
       size_t tmp3_bytes = 0, tmp4_bytes = 0;
-      uint32_t cutoff = 0, h_tail[2] = {0, 0}, h_haz = 0;
+      const uint32_t* d_cutoff = nullptr;
       int rc2 = PCM_OK;
 #define CK2(x)                                                                   \
   do {                                                                           \
@@ -442,23 +463,18 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       CK2(hipMallocAsync(&alive_s, sizeof(uint32_t) * n, stream));
       CK2(hipMallocAsync(&pos_s, sizeof(uint32_t) * n, stream));
       CK2(hipMallocAsync(&tmp_log, sizeof(float4) * n, stream));
-      CK2(hipMemsetAsync(vlast, 0, sizeof(uint32_t) * nvox, stream));
-      k_voxel_last<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, map->idx_s, vflag, vrank, n, vlast);
+      k_voxel_firsts<<<cdiv(n, 256), 256, 0, stream>>>(vflag, vrank, n, vfirst);
+      k_voxel_last_from_firsts<<<cdiv(nvox, 256), 256, 0, stream>>>(d_pts, map->idx_s, vfirst, nvox, n, vlast);
       CK2(hipGetLastError());
       CK2(rocprim::radix_sort_keys(nullptr, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
       CK2(hipMallocAsync(&tmp3, tmp3_bytes, stream));
       CK2(rocprim::radix_sort_keys(tmp3, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
-      CK2(hipMemcpyAsync(&cutoff, vsorted + (nvox - keep), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      CK2(hipStreamSynchronize(stream));
-      if (incremental) {   // the batch = the log points from n_indexed on; their sequence numbers start at the first one's
-        uint32_t seq0 = 0;
-        CK2(hipMemcpyAsync(&seq0, reinterpret_cast<const char*>(d_pts + n_indexed) + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        CK2(hipStreamSynchronize(stream));
-        k_voxel_firsts<<<cdiv(n, 256), 256, 0, stream>>>(vflag, vrank, n, vfirst);
-        k_lru_hazards<<<cdiv(nvox, 256), 256, 0, stream>>>(d_pts, map->idx_s, vfirst, nvox, n, seq0, cutoff, reinterpret_cast<unsigned int*>(d_flags + 3));
+      d_cutoff = vsorted + (nvox - keep);   // the smallest surviving last-touch stamp, read on the device
+      if (incremental && n_indexed < n) {   // the batch = the log points from n_indexed on
+        k_lru_hazards<<<cdiv(nvox, 256), 256, 0, stream>>>(d_pts, map->idx_s, vfirst, vlast, nvox, n, d_pts + n_indexed, d_cutoff, reinterpret_cast<unsigned int*>(d_flags + 3));
         CK2(hipGetLastError());
       }
-      k_mark_alive<<<cdiv(n, 256), 256, 0, stream>>>(map->idx_s, vflag, vrank, vlast, cutoff, n, alive);
+      k_mark_alive_dev<<<cdiv(n, 256), 256, 0, stream>>>(map->idx_s, vflag, vrank, vlast, d_cutoff, n, alive);
       CK2(hipGetLastError());
       CK2(rocprim::exclusive_scan(nullptr, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
       CK2(hipMallocAsync(&tmp4, tmp4_bytes, stream));
@@ -467,13 +483,12 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       { size_t tb = tmp4_bytes; CK2(rocprim::exclusive_scan(tmp4, tb, alive_s, pos_s, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream)); }
       k_compact_log<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, alive, pos, n, tmp_log);
       k_compact_index<<<cdiv(n, 256), 256, 0, stream>>>(map->keys_s, map->idx_s, alive, pos, pos_s, n, map->keys_t, map->idx_t);
+      k_count_alive<<<1, 1, 0, stream>>>(alive, pos, n, d_flags);
       CK2(hipGetLastError());
-      CK2(hipMemcpyAsync(&h_tail[0], pos + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      CK2(hipMemcpyAsync(&h_tail[1], alive + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      CK2(hipMemcpyAsync(&h_haz, d_flags + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      CK2(hipMemcpyAsync(map->h_ctr, d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
       CK2(hipStreamSynchronize(stream));
-      n = h_tail[0] + h_tail[1];
-      hazards = h_haz;
+      n = (uint32_t)map->h_ctr[5];
+      hazards = (uint32_t)map->h_ctr[3];
       CK2(hipMemcpyAsync(d_pts, tmp_log, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, stream));
       std::swap(map->keys_s, map->keys_t); std::swap(map->keys_cap, map->keys_t_cap);
       std::swap(map->idx_s, map->idx_t); std::swap(map->idx_cap, map->idx_t_cap);
@@ -513,9 +528,9 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     CK(hipGetLastError());
     k_gather_points<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, map->idx_s, map->keys_s, vrank, map->vox_start, n, map->pts);
     CK(hipGetLastError());
-    k_max_voxel_points<<<cdiv(nvox, 256), 256, 0, stream>>>(map->vox_start, nvox, reinterpret_cast<unsigned int*>(d_flags + 2));
+    k_max_voxel_points<<<cdiv(nvox, 1024), 256, 0, stream>>>(map->vox_start, nvox, reinterpret_cast<unsigned int*>(d_flags + 2));
     CK(hipGetLastError());
-    CK(hipMemcpyAsync(&map->max_voxel_points, d_flags + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));   // complete at the synchronize below
+    CK(hipMemcpyAsync(map->h_ctr, d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));   // complete at the synchronize below
     if (map->gvox) { (void)hipStreamSynchronize(stream); hipFree(map->gvox); map->gvox = nullptr; }
     if (map->order) { (void)hipStreamSynchronize(stream); hipFree(map->order); map->order = nullptr; }
     if (want_gauss) {
@@ -524,6 +539,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       CK(hipGetLastError());
     }
     CK(hipStreamSynchronize(stream));
+    map->max_voxel_points = (uint32_t)map->h_ctr[2];
     if (keep_order) {   // a persistent copy of the input index of every map point
       CK(hipMalloc(&map->order, sizeof(uint32_t) * (size_t)n));
       CK(hipMemcpyAsync(map->order, map->idx_s, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
