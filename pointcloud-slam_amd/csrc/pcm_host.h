@@ -43,6 +43,8 @@ struct TargetMap {   // layout: pcm_device.h
   size_t keys_cap = 0, keys_t_cap = 0, idx_cap = 0, idx_t_cap = 0, vox_cap = 0, pts_cap = 0;
   uint32_t bricks_cap = 0;      // allocated slots of bricks / bmask / bpref (cap <= bricks_cap is the table in use)
   uint32_t index_n = 0;         // log points keys_s / idx_s cover (0: no usable index)
+  char* arena = nullptr;        // scratch of the incremental updates (grow-only; voxel_hash.hip BuildScratch)
+  size_t arena_cap = 0;
   int* h_ctr = nullptr;         // pinned host copy of the build's counter record (one read-back per synchronisation point)
   uint32_t cap = 0, num_voxels = 0, num_bricks = 0, num_points = 0;
   uint32_t max_voxel_points = 0;   // most points in one voxel
@@ -62,6 +64,8 @@ struct TargetMap {   // layout: pcm_device.h
     if (idx_s) hipFree(idx_s);
     if (idx_t) hipFree(idx_t);
     if (h_ctr) hipHostFree(h_ctr);
+    if (arena) hipFree(arena);
+    arena = nullptr; arena_cap = 0;
     h_ctr = nullptr;
     gvox = nullptr; order = nullptr; keys_s = keys_t = nullptr; idx_s = idx_t = nullptr;
     bricks = nullptr; bmask = nullptr; bpref = nullptr; vox_start = nullptr; pts = nullptr;

@@ -48,6 +48,8 @@ __global__ void k_point_keys(const float4* __restrict__ pts, uint32_t n, float r
   idx[i] = i;
 }
 
+constexpr int kBrickCountShards = 32;   // counters of the brick heads (k_head_flags), summed on the host
+constexpr int kCtrInts = 8 + kBrickCountShards;   // the build's counter record: 8 scalars + the shards
 // voxel-head flags (input of the rank scan) + number of brick heads
 __global__ void k_head_flags(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ vflag, unsigned int* __restrict__ nbricks) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +66,7 @@ __global__ void k_head_flags(const uint64_t* __restrict__ keys, uint32_t n, uint
   const unsigned long long m = __ballot(bhead);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_cnt, (unsigned int)__popcll(m));
   __syncthreads();
-  if (threadIdx.x == 0 && s_cnt) atomicAdd(nbricks, s_cnt);
+  if (threadIdx.x == 0 && s_cnt) atomicAdd(nbricks + (blockIdx.x & (kBrickCountShards - 1)), s_cnt);   // sharded: one word took 130 us for 13 000 blocks
 }
 
 // one insertion per brick: the first point of each brick claims a slot
@@ -343,6 +345,26 @@ __global__ void k_voxel_firsts(const uint32_t* __restrict__ vflag, const uint32_
   if (i < n && vflag[i]) vox_first[vrank[i]] = i;
 }
 
+// Scratch of one build: a sliding map keeps a grow-only arena (an update then makes no allocation call at all: two dozen
+// hipMallocAsync / hipFreeAsync pairs were a third of an update's wall time); any other build takes from the stream-ordered pool.
+struct BuildScratch {
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+  std::vector<void*> pooled;
+  hipError_t get(void** p, size_t bytes, hipStream_t stream) {
+    const size_t b = (bytes + 255) & ~(size_t)255;
+    if (base && used + b <= cap) { *p = base + used; used += b; return hipSuccess; }
+    const hipError_t e = hipMallocAsync(p, bytes ? bytes : 1, stream);
+    if (e == hipSuccess) pooled.push_back(*p);
+    return e;
+  }
+  void release(hipStream_t stream) {
+    for (void* q : pooled) (void)hipFreeAsync(q, stream);
+    pooled.clear();
+    used = 0;
+  }
+};
+
 template <typename T>
 static int grow(T** p, size_t* cap, size_t need, size_t keep_elems, hipStream_t stream, std::string* err, const char* what) {
   if (need <= *cap) return PCM_OK;
@@ -374,6 +396,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   size_t tmp_bytes = 0, tmp2_bytes = 0;
   int rc = PCM_OK;
   uint32_t hazards = 0;
+  BuildScratch sc;
   // ivox3d.h:67  inv_resolution_ = 1.0 / resolution_ (float);  pcl::VoxelGrid: inverse_leaf_size_ = 1 / leaf_size_ in float
   const float inv_res = coord_mode == COORD_FLOOR_MUL ? 1.0f / res : (float)(1.0 / res);
 #define CK(x)                                                                    \
@@ -383,9 +406,21 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
   } while (0)
 #define RC(x) do { rc = (x); if (rc != PCM_OK) goto done; } while (0)
   map->valid = false;
-  if (!map->h_ctr && hipHostMalloc(reinterpret_cast<void**>(&map->h_ctr), 8 * sizeof(int)) != hipSuccess) { *err = "hipHostMalloc(counters)"; return PCM_ERR_HIP; }
-  CK(hipMallocAsync(&d_flags, 8 * sizeof(int), stream));
-  CK(hipMemsetAsync(d_flags, 0, 8 * sizeof(int), stream));
+  if (!map->h_ctr && hipHostMalloc(reinterpret_cast<void**>(&map->h_ctr), kCtrInts * sizeof(int)) != hipSuccess) { *err = "hipHostMalloc(counters)"; return PCM_ERR_HIP; }
+  if (incremental) {   // everything an update with eviction takes, rounded up: 24 B per new point, 52 B per log point, sort / scan temporaries
+    const size_t need = 24 * (size_t)(n - n_indexed) + 56 * (size_t)n + ((size_t)16 << 20);
+    if (need > map->arena_cap) {
+      (void)hipStreamSynchronize(stream);
+      if (map->arena) hipFree(map->arena);
+      map->arena = nullptr; map->arena_cap = 0;
+      const size_t nc = need + need / 4;
+      CK(hipMalloc(reinterpret_cast<void**>(&map->arena), nc));
+      map->arena_cap = nc;
+    }
+    sc.base = map->arena; sc.cap = map->arena_cap;
+  }
+  CK(sc.get(reinterpret_cast<void**>(&d_flags), kCtrInts * sizeof(int), stream));
+  CK(hipMemsetAsync(d_flags, 0, kCtrInts * sizeof(int), stream));
   {
     // ---- 1. the sorted index (key, log position) of all n log points in map->keys_s / idx_s ------------------------------
     const uint32_t first = incremental ? n_indexed : 0u, m = n - first;
@@ -394,16 +429,16 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     RC(grow(&map->keys_t, &map->keys_t_cap, n, 0, stream, err, "keys_t"));
     RC(grow(&map->idx_t, &map->idx_t_cap, n, 0, stream, err, "idx_t"));
     if (m > 0) {
-      CK(hipMallocAsync(&keys_b, sizeof(uint64_t) * m, stream));
-      CK(hipMallocAsync(&keys_bs, sizeof(uint64_t) * m, stream));
-      CK(hipMallocAsync(&idx_b, sizeof(uint32_t) * m, stream));
-      CK(hipMallocAsync(&idx_bs, sizeof(uint32_t) * m, stream));
+      CK(sc.get(reinterpret_cast<void**>(&keys_b), sizeof(uint64_t) * m, stream));
+      CK(sc.get(reinterpret_cast<void**>(&keys_bs), sizeof(uint64_t) * m, stream));
+      CK(sc.get(reinterpret_cast<void**>(&idx_b), sizeof(uint32_t) * m, stream));
+      CK(sc.get(reinterpret_cast<void**>(&idx_bs), sizeof(uint32_t) * m, stream));
       k_point_keys_at<<<cdiv(m, 256), 256, 0, stream>>>(d_pts, first, m, res, inv_res, coord_mode, keys_b, idx_b, d_flags);
       CK(hipGetLastError());
       uint64_t* ks = incremental ? keys_bs : map->keys_s;   // a full build sorts straight into the persistent index
       uint32_t* is = incremental ? idx_bs : map->idx_s;
       CK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_b, ks, idx_b, is, m, 0, 63, stream));
-      CK(hipMallocAsync(&tmp, tmp_bytes, stream));
+      CK(sc.get(reinterpret_cast<void**>(&tmp), tmp_bytes, stream));
       CK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_b, ks, idx_b, is, m, 0, 63, stream));
       if (incremental) {
         k_merge_old<<<cdiv(n_indexed, 256), 256, 0, stream>>>(map->keys_s, map->idx_s, n_indexed, keys_bs, m, map->keys_t, map->idx_t);
@@ -415,27 +450,28 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     }
     map->index_n = 0;   // until this build is through
     // ---- 2. voxel heads, ranks; counts to the host -----------------------------------------------------------------------
-    CK(hipMallocAsync(&vflag, sizeof(uint32_t) * n, stream));
-    CK(hipMallocAsync(&vrank, sizeof(uint32_t) * n, stream));
+    CK(sc.get(reinterpret_cast<void**>(&vflag), sizeof(uint32_t) * n, stream));
+    CK(sc.get(reinterpret_cast<void**>(&vrank), sizeof(uint32_t) * n, stream));
     uint32_t nvox = 0, nbricks = 0;
     auto heads = [&](uint32_t cnt) -> int {
-      CK(hipMemsetAsync(d_flags + 1, 0, sizeof(int), stream));
-      k_head_flags<<<cdiv(cnt, 256), 256, 0, stream>>>(map->keys_s, cnt, vflag, reinterpret_cast<unsigned int*>(d_flags + 1));
+      CK(hipMemsetAsync(d_flags + 8, 0, kBrickCountShards * sizeof(int), stream));
+      k_head_flags<<<cdiv(cnt, 256), 256, 0, stream>>>(map->keys_s, cnt, vflag, reinterpret_cast<unsigned int*>(d_flags + 8));
       CK(hipGetLastError());
       if (!tmp2) {
         CK(rocprim::exclusive_scan(nullptr, tmp2_bytes, vflag, vrank, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-        CK(hipMallocAsync(&tmp2, tmp2_bytes, stream));
+        CK(sc.get(reinterpret_cast<void**>(&tmp2), tmp2_bytes, stream));
       }
       {
         size_t tb = tmp2_bytes;
         CK(rocprim::exclusive_scan(tmp2, tb, vflag, vrank, 0u, (size_t)cnt, rocprim::plus<uint32_t>(), stream));
       }
       k_count_voxels<<<1, 1, 0, stream>>>(vflag, vrank, cnt, d_flags);
-      CK(hipMemcpyAsync(map->h_ctr, d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));   // one copy into pinned memory
+      CK(hipMemcpyAsync(map->h_ctr, d_flags, kCtrInts * sizeof(int), hipMemcpyDeviceToHost, stream));   // one copy into pinned memory
       CK(hipStreamSynchronize(stream));
       if (map->h_ctr[0]) { *err = "target point outside the +-2^20 voxel range (or not finite)"; rc = PCM_ERR_OUT_OF_RANGE; goto done; }
       nvox = (uint32_t)map->h_ctr[4];
-      nbricks = (uint32_t)map->h_ctr[1];
+      nbricks = 0;
+      for (int k = 0; k < kBrickCountShards; k++) nbricks += (uint32_t)map->h_ctr[8 + k];
       return PCM_OK;
     done:
       return rc;
@@ -455,19 +491,19 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     hipError_t e_ = (x);                                                         \
     if (e_ != hipSuccess) { *err = std::string(#x) + ": " + hipGetErrorString(e_); rc2 = PCM_ERR_HIP; goto evict_done; } \
   } while (0)
-      CK2(hipMallocAsync(&vlast, sizeof(uint32_t) * nvox, stream));
-      CK2(hipMallocAsync(&vsorted, sizeof(uint32_t) * nvox, stream));
-      CK2(hipMallocAsync(&vfirst, sizeof(uint32_t) * nvox, stream));
-      CK2(hipMallocAsync(&alive, sizeof(uint32_t) * n, stream));
-      CK2(hipMallocAsync(&pos, sizeof(uint32_t) * n, stream));
-      CK2(hipMallocAsync(&alive_s, sizeof(uint32_t) * n, stream));
-      CK2(hipMallocAsync(&pos_s, sizeof(uint32_t) * n, stream));
-      CK2(hipMallocAsync(&tmp_log, sizeof(float4) * n, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&vlast), sizeof(uint32_t) * nvox, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&vsorted), sizeof(uint32_t) * nvox, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&vfirst), sizeof(uint32_t) * nvox, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&alive), sizeof(uint32_t) * n, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&pos), sizeof(uint32_t) * n, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&alive_s), sizeof(uint32_t) * n, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&pos_s), sizeof(uint32_t) * n, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&tmp_log), sizeof(float4) * n, stream));
       k_voxel_firsts<<<cdiv(n, 256), 256, 0, stream>>>(vflag, vrank, n, vfirst);
       k_voxel_last_from_firsts<<<cdiv(nvox, 256), 256, 0, stream>>>(d_pts, map->idx_s, vfirst, nvox, n, vlast);
       CK2(hipGetLastError());
       CK2(rocprim::radix_sort_keys(nullptr, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
-      CK2(hipMallocAsync(&tmp3, tmp3_bytes, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&tmp3), tmp3_bytes, stream));
       CK2(rocprim::radix_sort_keys(tmp3, tmp3_bytes, vlast, vsorted, nvox, 0, 32, stream));
       d_cutoff = vsorted + (nvox - keep);   // the smallest surviving last-touch stamp, read on the device
       if (incremental && n_indexed < n) {   // the batch = the log points from n_indexed on
@@ -477,7 +513,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       k_mark_alive_dev<<<cdiv(n, 256), 256, 0, stream>>>(map->idx_s, vflag, vrank, vlast, d_cutoff, n, alive);
       CK2(hipGetLastError());
       CK2(rocprim::exclusive_scan(nullptr, tmp4_bytes, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
-      CK2(hipMallocAsync(&tmp4, tmp4_bytes, stream));
+      CK2(sc.get(reinterpret_cast<void**>(&tmp4), tmp4_bytes, stream));
       { size_t tb = tmp4_bytes; CK2(rocprim::exclusive_scan(tmp4, tb, alive, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream)); }
       k_alive_sorted<<<cdiv(n, 256), 256, 0, stream>>>(map->idx_s, alive, n, alive_s);
       { size_t tb = tmp4_bytes; CK2(rocprim::exclusive_scan(tmp4, tb, alive_s, pos_s, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream)); }
@@ -485,7 +521,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       k_compact_index<<<cdiv(n, 256), 256, 0, stream>>>(map->keys_s, map->idx_s, alive, pos, pos_s, n, map->keys_t, map->idx_t);
       k_count_alive<<<1, 1, 0, stream>>>(alive, pos, n, d_flags);
       CK2(hipGetLastError());
-      CK2(hipMemcpyAsync(map->h_ctr, d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
+      CK2(hipMemcpyAsync(map->h_ctr, d_flags, kCtrInts * sizeof(int), hipMemcpyDeviceToHost, stream));
       CK2(hipStreamSynchronize(stream));
       n = (uint32_t)map->h_ctr[5];
       hazards = (uint32_t)map->h_ctr[3];
@@ -494,8 +530,6 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       std::swap(map->idx_s, map->idx_t); std::swap(map->idx_cap, map->idx_t_cap);
       *n_inout = n;
     evict_done:
-      sfree(stream, vlast); sfree(stream, vsorted); sfree(stream, vfirst); sfree(stream, alive); sfree(stream, pos); sfree(stream, alive_s); sfree(stream, pos_s);
-      sfree(stream, tmp_log); sfree(stream, tmp3); sfree(stream, tmp4);
 #undef CK2
       if (rc2 != PCM_OK) { rc = rc2; goto done; }
       RC(heads(n));   // the survivors' voxel heads and ranks
@@ -530,7 +564,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     CK(hipGetLastError());
     k_max_voxel_points<<<cdiv(nvox, 1024), 256, 0, stream>>>(map->vox_start, nvox, reinterpret_cast<unsigned int*>(d_flags + 2));
     CK(hipGetLastError());
-    CK(hipMemcpyAsync(map->h_ctr, d_flags, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));   // complete at the synchronize below
+    CK(hipMemcpyAsync(map->h_ctr, d_flags, kCtrInts * sizeof(int), hipMemcpyDeviceToHost, stream));   // complete at the synchronize below
     if (map->gvox) { (void)hipStreamSynchronize(stream); hipFree(map->gvox); map->gvox = nullptr; }
     if (map->order) { (void)hipStreamSynchronize(stream); hipFree(map->order); map->order = nullptr; }
     if (want_gauss) {
@@ -556,7 +590,7 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     map->valid = true;
   }
 done:
-  sfree(stream, keys_b); sfree(stream, keys_bs); sfree(stream, idx_b); sfree(stream, idx_bs); sfree(stream, vflag); sfree(stream, vrank); sfree(stream, d_flags); sfree(stream, tmp); sfree(stream, tmp2);
+  sc.release(stream);
   if (lru_hazards) *lru_hazards = hazards;
   if (rc != PCM_OK) map->release();
   return rc;
