@@ -168,7 +168,8 @@ typedef struct pcm_stats {
   uint64_t lru_batch_hazards;    /* sliding map: voxels a batch touched whose previous touch was older than the batch's eviction cut-off -- the
                                   * reference's sequential LRU list (ivox3d.h:256-281) may have dropped such a voxel before the batch reached it
                                   * and re-created it with the batch's points only; the batch rule here keeps it whole.  0 = the map equals the
-                                  * sequential result (a LiDAR map's oldest voxels lie behind the sensor: never observed non-zero) */
+                                  * sequential result.  Conservative (every voxel that MIGHT differ is counted): 0-24 per frame out of 10^6
+                                  * voxels in the synthetic config-5 loops */
 } pcm_stats;
 
 typedef struct pcm_ctx pcm_ctx;
