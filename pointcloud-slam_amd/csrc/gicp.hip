@@ -223,25 +223,26 @@ __device__ inline void regularize_cov_f(int method, float (&c)[9]) {
 }
 
 // ---------------------------------------------------------------------------
-// k_covariances: one lane per map point, one wave per 64 CONSECUTIVE map points.  The map is
-// brick-major, so the 64 queries of a wave sit in neighbouring voxels and want nearly the same
-// candidates.  Per pass the wave takes the voxel box of its queries grown by r, spreads the box's
-// voxel-column segments over its lanes (one hash probe + mask word + two vox_start words per lane, all
-// 64 in flight together), prefix-sums the run lengths, stages the runs' points into LDS 256 at a time
-// and lets every lane scan the staged points (broadcast LDS reads) into its own k best.  A lane is
-// finished when its k-th distance lies inside its margin to the faces of the scanned box; the next r is
-// the largest radius an unfinished lane has proven (k points seen) or 4 r.  Lanes the box passes cannot
-// finish (r beyond 16 voxels, scattered waves) run the per-lane search.
-// dynamic LDS: 4 x (256 staged points + 65 offsets + 64 run starts); the k best of a lane are registers
+// k_covariances: 64 CONSECUTIVE map points per WORKGROUP, one query per lane, the four waves of the workgroup sharing the SAME 64
+// queries and splitting the candidates.  The map is brick-major, so the 64 queries sit in neighbouring voxels and want nearly the
+// same candidates.  Per pass the workgroup takes the voxel box of its queries grown by r, spreads the box's voxel-column segments
+// over its 256 lanes (one hash probe + mask word + two vox_start words per lane, all in flight together), prefix-sums the run
+// lengths, stages the runs' points into LDS 1024 at a time, and every wave scans its quarter of the staged points (broadcast LDS
+// reads) into the k best of its lanes -- per query four partial lists.  A query is finished when the smallest of its four k-th
+// distances (an upper bound of the true k-th) lies inside its margin to the faces of the scanned box; the next r is the largest
+// radius an unfinished query has proven (k points seen) or 1.25 r.  At the end wave 0 folds the other three lists into its own
+// and computes the covariances.  (One wave per 64 queries, round 2: a 100 k-point scan is 1 564 waves on 1 024 SIMDs, every one
+// of them a serial chain of probe rounds and scans -- mean 550 us, slowest 2 ms = the kernel; the chip was idle.)
+// Queries the box passes cannot finish (r beyond 16 voxels, scattered workgroups) run the per-lane search in wave 0.
+// dynamic LDS: 1024 staged points + 257 offsets + 256 run starts + exchange words; re-used for the final merge
 // ---------------------------------------------------------------------------
-constexpr int kStageCap = 256;
-constexpr int kWaveLds = kStageCap * 16 + 80 * 4 + 64 * 4;   // bytes per wave
-
-__device__ inline void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+constexpr int kStageCap = 1024;
+constexpr int kCovLdsFixed = kStageCap * 16 + 264 * 4 + 256 * 4 + 8 * 4 + 2 * 4 * 64 * 4;   // staging, soff, sps, wave sums, k-th distances, list fills
+__host__ __device__ constexpr size_t cov_lds_bytes(int kcap) {
+  const size_t merge = (size_t)3 * kcap * 64 * 8;   // three waves' lists, (distance, index) per slot
+  return (merge > (size_t)kStageCap * 16 ? merge : (size_t)kStageCap * 16) + (kCovLdsFixed - kStageCap * 16);
 }
+
 __device__ inline float wave_min_f(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
@@ -253,28 +254,53 @@ __device__ inline float wave_max_f(float v) {
   return v;
 }
 
+#ifdef PCM_COV_STATS   // diagnostic build only (tools/r03_cov_stats.sh): where the passes of k_covariances go
+__device__ unsigned long long g_cov_stats[32];
+#define COV_T0() const unsigned long long t_ph0 = wall_clock64()
+#define COV_T(i) do { if (threadIdx.x == 0) atomicAdd(&g_cov_stats[i], wall_clock64() - t_ph0); } while (0)
+#define COV_STAT(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_cov_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define COV_STAT(i, v) do { } while (0)
+#define COV_T0() do { } while (0)
+#define COV_T(i) do { } while (0)
+#endif
+
 template <int KCAP>
-__global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetView tg, int mode, int k, int reg, double* __restrict__ out) {
+__global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetView tg, TargetView tf, const uint32_t* __restrict__ f_order, const uint32_t* __restrict__ c_inv, int mode, int k,
+                                                                      int reg, double* __restrict__ out) {
   extern __shared__ uint64_t s_dyn[];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  char* wbase = reinterpret_cast<char*>(s_dyn) + (size_t)(tid >> 6) * kWaveLds;
-  float4* st = reinterpret_cast<float4*>(wbase);
-  uint32_t* soff = reinterpret_cast<uint32_t*>(wbase + kStageCap * 16);   // [65] exclusive offsets of the chunk's runs
-  uint32_t* sps = soff + 80;                                              // [64] first point of each run
-  const uint32_t i = blockIdx.x * 256 + tid;
-  const bool active = i < tg.num_points;
-  const float4 pq = gload4(tg.pts + (active ? i : tg.num_points - 1u));
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  char* const lbase = reinterpret_cast<char*>(s_dyn);
+  const size_t stage_bytes = cov_lds_bytes(KCAP) - (kCovLdsFixed - kStageCap * 16);
+  float4* st = reinterpret_cast<float4*>(lbase);                          // [1024] staged points (the merge area later)
+  uint32_t* soff = reinterpret_cast<uint32_t*>(lbase + stage_bytes);      // [257] exclusive offsets of the round's runs
+  uint32_t* sps = soff + 264;                                             // [256] first point of each run
+  uint32_t* s_wsum = sps + 256;                                           // [4] run-length totals of the waves
+  float* s_dk = reinterpret_cast<float*>(s_wsum + 8);                     // [4][64] k-th distance of every wave's partial list
+  int* s_fill = reinterpret_cast<int*>(s_dk + 256);                       // [4][64] points in every wave's partial list
+  // With a fine index (tf) the queries are taken in ITS order -- 64 consecutive points of a 1/8-size grid are one small patch even
+  // where a whole voxel of the map's own grid holds thousands of points in insertion order -- and the row goes to the query's place
+  // in the map (c_inv[f_order[.]]: fine position -> input index -> map position).
+  const bool has_fine = tf.num_points != 0u;
+  const uint32_t i = blockIdx.x * 64 + lane;
+  const uint32_t nq = has_fine ? tf.num_points : tg.num_points;
+  const bool active = i < nq;
+  const float4 pq = gload4((has_fine ? tf.pts : tg.pts) + (active ? i : nq - 1u));
+  const uint32_t oi = !active ? 0u : has_fine ? gload_u(c_inv + gload_u(f_order + i)) : i;
   const float q[3] = {pq.x, pq.y, pq.z};
   // The k best of a lane live in registers, sorted ascending in the LAST k of KCAP slots (the slots in
   // front hold a -1 sentinel no distance undercuts): the k-th best is always bd[KCAP - 1], and an
   // insertion is a branch-free shift network -- no LDS round trip per shifted element.
   float bd[KCAP];
   uint32_t bi[KCAP];
-  auto reset = [&]() {
+  // `cap`: only candidates strictly nearer than sqrt(cap) are kept.  Without one every staged point enters some lane's list while
+  // the lists fill, and the shift network below runs for the whole wave whenever ANY lane inserts: ~1 800 staged points per pass,
+  // ~68 instructions each, for the ~170 that end up mattering.  A slot that holds no point yet carries the cap and bi = ~0u.
+  auto reset = [&](float cap) {
 #pragma unroll
-    for (int j = 0; j < KCAP; j++) { bd[j] = j < KCAP - k ? -1.f : 3.0e38f; bi[j] = ~0u; }
+    for (int j = 0; j < KCAP; j++) { bd[j] = j < KCAP - k ? -1.f : cap; bi[j] = ~0u; }
   };
-  reset();
+  reset(3.0e38f);
   auto visit = [&](uint32_t p, float d2) {
     if (!(d2 < bd[KCAP - 1])) return;   // also rejects NaN; an exact tie with the k-th keeps the earlier point
     bool c_cur = true;                  // d2 < bd[j] (old value)
@@ -287,32 +313,34 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
     }
     if (c_cur) { bd[0] = d2; bi[0] = p; }
   };
-  bool exact = !active;   // lanes past the end only help with the staging
-  // A wave whose queries are far apart in space (the brick order jumps) is served in groups of lanes
-  // within 8 voxels of the first pending lane: each group gets its own box passes, the others only help staging.
-  uint64_t pending = __ballot(active);
-  for (int grp = 0; grp < 8 && pending != 0ull; grp++) {
-    const int lead = __ffsll((unsigned long long)pending) - 1;
-    bool mine = active && ((pending >> lane) & 1ull);
-#pragma unroll
-    for (int a = 0; a < 3; a++) mine = mine && fabsf(q[a] - __shfl(q[a], lead, 64)) <= 8.f * tg.res;
-    pending &= ~__ballot(mine);
+  const float shift = mode == COORD_ROUND ? -0.5f : 0.5f;   // voxel c covers [(c + shift) res, (c + shift + 1) res]
+  // Box passes of the queries `mine` over the grid `tv`.  Every decision below is taken from values all four waves hold alike (the
+  // same queries, the same reductions), so the workgroup's control flow is uniform and the barriers are safe.  Returns, per lane,
+  // whether the k best of its query -- spread over the four waves' lists -- are exact (true for lanes outside `mine`).
+  auto box_passes = [&](const TargetView& tv, bool mine, float r, const float rmax, const float (&bmin)[3], const float (&bmax)[3], int stat0) -> bool {
     bool gexact = !mine;
-    float bmin[3], bmax[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) { bmin[a] = wave_min_f(mine ? q[a] : 3.0e38f); bmax[a] = wave_max_f(mine ? q[a] : -3.0e38f); }
-    const float lim = (float)(kCoordBias - 64) * tg.res;
-    const float shift = mode == COORD_ROUND ? -0.5f : 0.5f;   // voxel c covers [(c + shift) res, (c + shift + 1) res]
-    const bool finite = isfinite(bmin[0]) && isfinite(bmin[1]) && isfinite(bmin[2]) && isfinite(bmax[0]) && isfinite(bmax[1]) && isfinite(bmax[2]);
+    const float lim = (float)(kCoordBias - 64) * tv.res;
     int plo[3] = {0, 0, 0}, phi[3] = {-1, -1, -1};
-    float r = 0.25f * tg.res;
-    const float rmax = 16.f * tg.res;
-    while (finite && r <= rmax && __ballot(!gexact) != 0ull) {
+    // the radius that holds k points, estimated from the queries' own patch: n queries on an area e1 x e2 (the two larger extents
+    // of their box) -> surface density -> disc with k points.  It sizes the first box (1.3 x) and caps the first pass's lists (2 x);
+    // a wrong estimate costs a pass, never the result: a list that did not fill below its cap proves nothing and the pass is redone.
+    float capl = 3.0e38f;
+    {
+      const float e0 = bmax[0] - bmin[0], e1 = bmax[1] - bmin[1], e2 = bmax[2] - bmin[2];
+      const float emax = fmaxf(e0, fmaxf(e1, e2)), emin = fminf(e0, fminf(e1, e2)), emid = (e0 + e1 + e2) - emax - emin;
+      const float nm = (float)__popcll(__ballot(mine));
+      const float r_est = sqrtf((float)k * emax * emid / (3.14159265f * fmaxf(nm, 1.f)));
+      if (r_est > 0.f && r_est < rmax) {
+        r = fmaxf(r, 1.3f * r_est);
+        capl = 4.f * r_est * r_est;
+      }
+    }
+    while (r <= rmax && __ballot(!gexact) != 0ull) {
       int lo[3], hi[3];
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        lo[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmin[a] - r, -lim), lim), tg.res, tg.inv_res, mode));
-        hi[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmax[a] + r, -lim), lim), tg.res, tg.inv_res, mode));
+        lo[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmin[a] - r, -lim), lim), tv.res, tv.inv_res, mode));
+        hi[a] = __builtin_amdgcn_readfirstlane(voxel_coord(fminf(fmaxf(bmax[a] + r, -lim), lim), tv.res, tv.inv_res, mode));
       }
       if (lo[0] == plo[0] && lo[1] == plo[1] && lo[2] == plo[2] && hi[0] == phi[0] && hi[1] == phi[1] && hi[2] == phi[2]) { r *= 1.5f; continue; }
 #pragma unroll
@@ -320,34 +348,36 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
       const int nx = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, bz_lo = lo[2] >> kBrickShift, nbz = (hi[2] >> kBrickShift) - bz_lo + 1;
       if (nx > 64 || ny > 64 || nbz > 8 || nx * ny * nbz > 4096) break;   // scattered queries: per-lane search
       const int nseg = nx * ny * nbz;
-      if (!gexact) reset();
-      for (int segbase = 0; segbase < nseg; segbase += 64) {
-        // ---- one voxel-column segment (x, y, brick-z) per lane ----
-        const int sg = segbase + (int)lane;
+      if (!gexact) reset(capl);
+      COV_STAT(stat0, 1); COV_STAT(stat0 + 1, (nseg + 255) / 256);
+      for (int segbase = 0; segbase < nseg; segbase += 256) {
+        // ---- one voxel-column segment (x, y, brick-z) per lane of the workgroup ----
+        const int sg = segbase + (int)tid;
         uint32_t cnt = 0, ps = 0;
+        COV_T0();
         if (sg < nseg) {
           const int ibz = sg % nbz, t2 = sg / nbz, iy = t2 % ny, ix = t2 / ny;
           const int x = lo[0] + ix, y = lo[1] + iy, bz = bz_lo + ibz;
           const int z0 = (lo[2] > bz * 8 ? lo[2] : bz * 8) & 7, z1 = (hi[2] < bz * 8 + 7 ? hi[2] : bz * 8 + 7) & 7;
           const int bx = x >> kBrickShift, by = y >> kBrickShift;
           const uint64_t key = pack_brick(bx, by, bz);
-          uint32_t h = hash_coord(bx, by, bz) & tg.mask;
+          uint32_t h = hash_coord(bx, by, bz) & tv.mask;
           for (;;) {
-            const uint4 sl = gload4u(&tg.bricks[h]);
+            const uint4 sl = gload4u(&tv.bricks[h]);
             const uint64_t sk = slot_key(sl);
             if (sk == key) {
               const uint32_t w = (uint32_t)((x & 7) * 2 + ((y & 7) >> 2)), sh = (uint32_t)(((y & 7) & 3) * 8 + z0);
-              const uint32_t m = gload_u(&tg.bmask[(size_t)h * 16 + w]);
+              const uint32_t m = gload_u(&tv.bmask[(size_t)h * 16 + w]);
               const uint32_t sel = m & (((1u << (z1 - z0 + 1)) - 1u) << sh);
               if (sel) {
-                const uint32_t vs = sl.z + gload_u16(&tg.bpref[(size_t)h * 16 + w]) + (uint32_t)__popc(m & ((1u << sh) - 1u));
-                ps = gload_u(&tg.vox_start[vs]);
-                cnt = gload_u(&tg.vox_start[vs + (uint32_t)__popc(sel)]) - ps;
+                const uint32_t vs = sl.z + gload_u16(&tv.bpref[(size_t)h * 16 + w]) + (uint32_t)__popc(m & ((1u << sh) - 1u));
+                ps = gload_u(&tv.vox_start[vs]);
+                cnt = gload_u(&tv.vox_start[vs + (uint32_t)__popc(sel)]) - ps;
               }
               break;
             }
             if (sk == kEmptyKey) break;
-            h = (h + 1) & tg.mask;
+            h = (h + 1) & tv.mask;
           }
         }
         uint32_t incl = cnt;
@@ -356,58 +386,140 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
           const uint32_t t = __shfl_up(incl, off, 64);
           if ((int)lane >= off) incl += t;
         }
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        if (total == 0u) continue;
-        soff[lane] = incl - cnt;
-        sps[lane] = ps;
-        if (lane == 0) soff[64] = total;
-        wave_sync();
-        // ---- stage the runs' points 256 at a time; every unfinished lane scans them ----
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();   // also: the previous round's staged points have been scanned by every wave
+        COV_T(24);
+        const uint32_t w0 = s_wsum[0], w1 = s_wsum[1], w2 = s_wsum[2], w3 = s_wsum[3];
+        const uint32_t total = w0 + w1 + w2 + w3;
+        if (total == 0u) { __syncthreads(); continue; }   // s_wsum is rewritten by the next round
+        COV_STAT(stat0 + 2, total);
+        const uint32_t wbase = wave == 0 ? 0u : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
+        soff[tid] = wbase + incl - cnt;
+        sps[tid] = ps;
+        if (tid == 0) soff[256] = total;
+        __syncthreads();
+        // ---- stage the runs' points 1024 at a time; every wave scans its quarter for its unfinished lanes ----
         for (uint32_t r0 = 0; r0 < total; r0 += kStageCap) {
           const uint32_t nst = total - r0 < (uint32_t)kStageCap ? total - r0 : (uint32_t)kStageCap;
-          for (uint32_t t = r0 + lane; t < r0 + nst; t += 64) {
+          COV_T0();
+          for (uint32_t t = r0 + tid; t < r0 + nst; t += 256) {
             uint32_t a = 0;   // run of staged point t: the last one whose offset is <= t
 #pragma unroll
-            for (uint32_t step = 32; step >= 1; step >>= 1) { if (soff[a + step] <= t) a += step; }
+            for (uint32_t step = 128; step >= 1; step >>= 1) { if (soff[a + step] <= t) a += step; }
             const uint32_t p = sps[a] + (t - soff[a]);
-            float4 c = gload4(tg.pts + p);
+            float4 c = gload4(tv.pts + p);
             c.w = __uint_as_float(p);
             st[t - r0] = c;
           }
-          wave_sync();
+          __syncthreads();
+          COV_T(25);
           if (!gexact) {
-            for (uint32_t j = 0; j < nst; j++) {
+            for (uint32_t j = wave; j < nst; j += 4) {
               const float4 c = st[j];
               const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
               visit(__float_as_uint(c.w), ex * ex + ey * ey + ez * ez);
             }
           }
-          wave_sync();
+          __syncthreads();
+          COV_T(26);   // staging + scan
         }
       }
       // margin of this lane to the faces of the scanned voxel box: every unseen point is farther away
       float mg = 3.0e38f;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const float slack = 1e-4f * tg.res + 4e-6f * fabsf(q[a]);
-        const float wlo = ((float)lo[a] + shift) * tg.res, whi = ((float)hi[a] + shift + 1.f) * tg.res;
+        const float slack = 1e-4f * tv.res + 4e-6f * fabsf(q[a]);
+        const float wlo = ((float)lo[a] + shift) * tv.res, whi = ((float)hi[a] + shift + 1.f) * tv.res;
         mg = fminf(mg, fminf(q[a] - wlo, whi - q[a]) - slack);
       }
+      // an upper bound of the query's true k-th distance: the smallest k-th of a partial list that is full, or the cap when the four
+      // lists together hold k points (all of them nearer than the cap)
+      int fill = 0;
+#pragma unroll
+      for (int j = 0; j < KCAP; j++) fill += (j >= KCAP - k && bi[j] != ~0u) ? 1 : 0;
+      s_dk[wave * 64 + lane] = fill == k ? bd[KCAP - 1] : 3.0e38f;
+      s_fill[wave * 64 + lane] = fill;
+      __syncthreads();
+      float d2k = fminf(fminf(s_dk[lane], s_dk[64 + lane]), fminf(s_dk[128 + lane], s_dk[192 + lane]));
+      if (s_fill[lane] + s_fill[64 + lane] + s_fill[128 + lane] + s_fill[192 + lane] >= k) d2k = fminf(d2k, capl);
+      __syncthreads();
       float need = 0.f;
       if (!gexact) {
-        const float d2k = bd[KCAP - 1];   // finite <=> k points seen
-        if (mg > 0.f && d2k < mg * mg) gexact = true;
-        else need = d2k < 3.0e38f ? sqrtf(d2k) * 1.001f : 2.f * r;   // k points seen: they lie inside this radius
+        const bool seen = d2k < 3.0e38f;
+        if (seen && mg > 0.f && d2k < mg * mg) gexact = true;
+        else {
+          need = seen ? sqrtf(d2k) * 1.001f : 2.f * r;   // k points seen: they lie inside this radius
+          capl = seen ? need * need : 3.0e38f;            // ... and strictly inside the next pass's cap
+        }
       }
       r = fmaxf(wave_max_f(need), 1.25f * r);
     }
+    return gexact;
+  };
+  bool exact = !active;   // lanes past the end only help with the staging
+  bool from_fine = false;
+  COV_STAT(0, 1);
+#ifdef PCM_COV_STATS
+  const unsigned long long t_wave0 = wall_clock64();
+#endif
+  if (has_fine) {
+    // ---- the fine grid first: worth it where the radius that holds k points is a fraction of the map's own voxel --------------
+    float bmin[3], bmax[3], e[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bmin[a] = wave_min_f(active ? q[a] : 3.0e38f); bmax[a] = wave_max_f(active ? q[a] : -3.0e38f); e[a] = bmax[a] - bmin[a]; }
+    const bool finite = isfinite(bmin[0]) && isfinite(bmin[1]) && isfinite(bmin[2]) && isfinite(bmax[0]) && isfinite(bmax[1]) && isfinite(bmax[2]);
+    const float emax = fmaxf(e[0], fmaxf(e[1], e[2])), emin = fminf(e[0], fminf(e[1], e[2]));
+    const float emid = (e[0] + e[1] + e[2]) - emax - emin;
+    const float nact = (float)__popcll(__ballot(active));
+    const float r_est = 1.3f * sqrtf((float)k * emax * emid / (3.14159265f * nact));
+    if (finite && emax <= 8.f * tf.res && r_est <= 2.f * tf.res) {
+      COV_STAT(1, 1);
+      const bool ok = box_passes(tf, active, 0.25f * tf.res, 4.f * tf.res, bmin, bmax, 2);
+      if (active) {
+        if (ok) { exact = true; from_fine = true; }
+        else reset(3.0e38f);
+      }
+    }
+  }
+  // A workgroup whose queries are far apart in space (the brick order jumps) is served in groups of lanes
+  // within 8 voxels of the first pending lane: each group gets its own box passes, the others only help staging.
+  uint64_t pending = __ballot(active && !exact);
+  for (int grp = 0; grp < 8 && pending != 0ull; grp++) {
+    const int lead = __ffsll((unsigned long long)pending) - 1;
+    bool mine = active && ((pending >> lane) & 1ull);
+#pragma unroll
+    for (int a = 0; a < 3; a++) mine = mine && fabsf(q[a] - __shfl(q[a], lead, 64)) <= 8.f * tg.res;
+    pending &= ~__ballot(mine);
+    float bmin[3], bmax[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { bmin[a] = wave_min_f(mine ? q[a] : 3.0e38f); bmax[a] = wave_max_f(mine ? q[a] : -3.0e38f); }
+    const bool finite = isfinite(bmin[0]) && isfinite(bmin[1]) && isfinite(bmin[2]) && isfinite(bmax[0]) && isfinite(bmax[1]) && isfinite(bmax[2]);
+    bool gexact = !mine;
+    COV_STAT(6, 1);
+    if (finite) gexact = box_passes(tg, mine, 0.25f * tg.res, 16.f * tg.res, bmin, bmax, 7);
     if (mine) exact = gexact;
   }
-  if (!exact) {   // per-lane search (sparse neighbourhoods, scattered waves)
-    float r = bd[KCAP - 1] < 3.0e38f ? sqrtf(bd[KCAP - 1]) * 1.001f : 2.f * tg.res;
+  // queries the box passes left open: the per-lane search below, by wave 0 alone (it rebuilds the whole list; the other waves'
+  // partial lists of such a query are dropped)
+  if (!exact && wave != 0) reset(3.0e38f);
+  COV_STAT(10, __popcll(__ballot(!exact)));
+#ifdef PCM_COV_STATS
+  {   // search time of this wave (100 MHz ticks): sum, max, histogram < 50 / 200 / 800 / 3200 us / more; by path
+    const unsigned long long dt = wall_clock64() - t_wave0;
+    if (threadIdx.x == 0) {
+      atomicAdd(&g_cov_stats[11], dt);
+      atomicMax(&g_cov_stats[12], dt);
+      const int b = dt < 5000 ? 0 : dt < 20000 ? 1 : dt < 80000 ? 2 : dt < 320000 ? 3 : 4;
+      atomicAdd(&g_cov_stats[13 + b], 1ull);
+      atomicAdd(&g_cov_stats[18 + b], dt);
+    }
+  }
+#endif
+  if (!exact && wave == 0) {   // per-lane search (sparse neighbourhoods, scattered workgroups)
+    float r = bi[KCAP - 1] != ~0u ? sqrtf(bd[KCAP - 1]) * 1.001f : 2.f * tg.res;   // a full (partial) list: k points within its k-th distance
     for (;;) {
       if (r > 32.f * tg.res) break;
-      reset();
+      reset(3.0e38f);
       scan_box(tg, mode, q, r * 1.0001f, visit);
       float rn = 2.f * r;
       if (bd[KCAP - 1] < 3.0e38f) {
@@ -417,11 +529,32 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
       r = rn;
     }
     if (!exact) {
-      reset();
+      reset(3.0e38f);
       scan_all(tg, mode, q, [&]() { return bd[KCAP - 1]; }, visit);
     }
   }
+  // ---- wave 0 folds the other waves' partial lists into its own (the staging area is free now) ----
+  {
+    uint2* mg2 = reinterpret_cast<uint2*>(lbase);   // [3][KCAP][64]
+    __syncthreads();
+    if (wave != 0) {
+#pragma unroll
+      for (int j = 0; j < KCAP; j++) mg2[((wave - 1) * KCAP + j) * 64 + lane] = make_uint2(__float_as_uint(bd[j]), bi[j]);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 0; w < 3; w++) {
+      for (int j = KCAP - k; j < KCAP; j++) {
+        const uint2 e2 = mg2[(w * KCAP + j) * 64 + lane];
+        if (e2.y != ~0u) visit(e2.y, __uint_as_float(e2.x));
+      }
+    }
+  }
+#ifdef PCM_COV_STATS
+  if (threadIdx.x == 0) atomicAdd(&g_cov_stats[27], wall_clock64() - t_wave0);   // search + merge
+#endif
   if (!active) return;
+  const float4* nb = from_fine ? tf.pts : tg.pts;   // bi[] index the grid that answered
   if (reg >= 16) {
     // CUDA-core semantics (PCM_MODEL_VGICP_CUDA): float sums over the neighbours nearest first, cov = S / k - mean mean^T
     // (covariance_estimation.cu:16-42), float regularisation; the 9 floats of the (not exactly symmetric) result go into
@@ -430,7 +563,7 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
 #pragma unroll
     for (int j = 0; j < KCAP; j++) {
       if (j >= KCAP - k && bi[j] != ~0u) {
-        const float4 c = gload4(tg.pts + bi[j]);
+        const float4 c = gload4(nb + bi[j]);
         const float x[3] = {c.x, c.y, c.z};
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -448,7 +581,7 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
       for (int b = 0; b < 3; b++) cf[a * 3 + b] = cf[a * 3 + b] / (float)k - meanf[a] * meanf[b];
     }
     regularize_cov_f(reg - 16, cf);
-    float* of = reinterpret_cast<float*>(out + (size_t)i * 6);
+    float* of = reinterpret_cast<float*>(out + (size_t)oi * 6);
 #pragma unroll
     for (int a = 0; a < 9; a++) gstore_f(of + a, cf[a]);
     return;
@@ -460,7 +593,7 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
 #pragma unroll
     for (int j = 0; j < KCAP; j++) {
       if (j >= KCAP - k && bi[j] != ~0u) {
-        const float4 c = gload4(tg.pts + bi[j]);
+        const float4 c = gload4(nb + bi[j]);
         const float x[3] = {c.x, c.y, c.z};
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -492,7 +625,7 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
         for (int b = 0; b < 3; b++) R[a * 3 + b] += (val[kk] * U[a * 3 + kk]) * U[b * 3 + kk];
       }
     }
-    double* o = out + (size_t)i * 6;
+    double* o = out + (size_t)oi * 6;
     gstore_d(o + 0, R[0]); gstore_d(o + 1, R[1]); gstore_d(o + 2, R[2]);
     gstore_d(o + 3, R[4]); gstore_d(o + 4, R[5]); gstore_d(o + 5, R[8]);
     return;
@@ -501,7 +634,7 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
 #pragma unroll
   for (int j = 0; j < KCAP; j++) {
     if (j >= KCAP - k && bi[j] != ~0u) {
-      const float4 c = gload4(tg.pts + bi[j]);
+      const float4 c = gload4(nb + bi[j]);
       mean[0] += (double)c.x; mean[1] += (double)c.y; mean[2] += (double)c.z;
     }
   }
@@ -510,7 +643,7 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
 #pragma unroll
   for (int j = 0; j < KCAP; j++) {
     if (j >= KCAP - k && bi[j] != ~0u) {
-      const float4 c = gload4(tg.pts + bi[j]);
+      const float4 c = gload4(nb + bi[j]);
       const double d[3] = {(double)c.x - mean[0], (double)c.y - mean[1], (double)c.z - mean[2]};
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -523,9 +656,12 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
   for (int a = 0; a < 9; a++) cov[a] /= (double)k;
   double R[9];
   regularize_cov(reg, cov, R);
-  double* o = out + (size_t)i * 6;
+  double* o = out + (size_t)oi * 6;
   gstore_d(o + 0, R[0]); gstore_d(o + 1, R[1]); gstore_d(o + 2, R[2]);
   gstore_d(o + 3, R[4]); gstore_d(o + 4, R[5]); gstore_d(o + 5, R[8]);
+#ifdef PCM_COV_STATS
+  if (threadIdx.x == 0) atomicAdd(&g_cov_stats[28], wall_clock64() - t_wave0);   // whole workgroup
+#endif
 }
 
 // voxel distributions of the VGICP map: a voxel's points are one run in input order
@@ -773,15 +909,48 @@ TargetView view_of(const TargetMap& m) {
 
 }  // namespace
 
-// regularised kNN covariance of every point of `map` (map order), 6 doubles each
-int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err) {   // regularization + 16: CUDA-core float semantics
+namespace {
+__global__ void k_invert_order(const uint32_t* __restrict__ order, uint32_t n, uint32_t* __restrict__ inv) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[order[i]] = i;
+}
+}  // namespace
+
+// regularised kNN covariance of every point of `map` (map order), 6 doubles each.  `fine`: a second index of the SAME points on a
+// finer grid, both built with keep_order -- the kNN search of dense neighbourhoods runs on it (see k_covariances).
+int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err, const TargetMap* fine) {   // regularization + 16: CUDA-core float semantics
   if (k < 1 || k > 64) { *err = "k_correspondences must be in [1, 64]"; return PCM_ERR_INVALID_ARGUMENT; }
-  const size_t lds = 4 * (size_t)kWaveLds;
-  const dim3 grid((map.num_points + 255) / 256);
-  if (k <= 20) k_covariances<20><<<grid, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
-  else if (k <= 32) k_covariances<32><<<grid, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
-  else k_covariances<64><<<grid, 256, lds, stream>>>(view_of(map), map.coord_mode, k, regularization, d_out);
+  const dim3 grid((map.num_points + 63) / 64);   // 64 queries per workgroup
+  const dim3 grid256((map.num_points + 255) / 256);
+  TargetView tf{};
+  uint32_t* c_inv = nullptr;
+  const uint32_t* f_order = nullptr;
+  if (fine && fine->valid && fine->order && map.order && fine->num_points == map.num_points) {
+    if (hipMallocAsync(reinterpret_cast<void**>(&c_inv), sizeof(uint32_t) * (size_t)map.num_points, stream) != hipSuccess) { *err = "hipMallocAsync(c_inv)"; return PCM_ERR_HIP; }
+    k_invert_order<<<grid256, 256, 0, stream>>>(map.order, map.num_points, c_inv);
+    tf = view_of(*fine);
+    f_order = fine->order;
+  }
+  if (k <= 20) k_covariances<20><<<grid, 256, cov_lds_bytes(20), stream>>>(view_of(map), tf, f_order, c_inv, map.coord_mode, k, regularization, d_out);
+  else if (k <= 32) k_covariances<32><<<grid, 256, cov_lds_bytes(32), stream>>>(view_of(map), tf, f_order, c_inv, map.coord_mode, k, regularization, d_out);
+  else k_covariances<64><<<grid, 256, cov_lds_bytes(64), stream>>>(view_of(map), tf, f_order, c_inv, map.coord_mode, k, regularization, d_out);
   const hipError_t e = hipGetLastError();
+#ifdef PCM_COV_STATS
+  {
+    unsigned long long h[32];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cov_stats), sizeof(h));
+    fprintf(stderr, "cov_stats n %u: waves %llu | fine attempts %llu passes %llu seg-rounds %llu candidates %llu exact lanes %llu | coarse groups %llu passes %llu seg-rounds %llu candidates %llu | per-lane %llu\n",
+            map.num_points, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10]);
+    fprintf(stderr, "cov_time n %u: search us per wave mean %.1f max %.1f | waves <50us %llu <200 %llu <800 %llu <3200 %llu more %llu | their us %.0f %.0f %.0f %.0f %.0f\n", map.num_points,
+            h[0] ? 0.01 * h[11] / h[0] : 0.0, 0.01 * h[12], h[13], h[14], h[15], h[16], h[17], 0.01 * h[18], 0.01 * h[19], 0.01 * h[20], 0.01 * h[21], 0.01 * h[22]);
+    fprintf(stderr, "cov_phase n %u: us per workgroup: probe rounds %.1f, staging %.1f, staging+scan %.1f, search+merge %.1f, whole %.1f\n", map.num_points, 0.01 * h[24] / h[0], 0.01 * h[25] / h[0],
+            0.01 * h[26] / h[0], 0.01 * h[27] / h[0], 0.01 * h[28] / h[0]);
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cov_stats), z, sizeof(z));
+  }
+#endif
+  if (c_inv) (void)hipFreeAsync(c_inv, stream);
   if (e != hipSuccess) { *err = std::string("k_covariances: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
   return PCM_OK;
 }

@@ -51,7 +51,8 @@ __device__ inline int leaf_lookup(const TargetView& tg, int vx, int vy, int vz) 
 }
 
 // second pass of applyFilter: one lane per voxel, its points in input order   :206-259, 262-366
-__global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, uint32_t nvox, PclLeaf* __restrict__ out) {
+__global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, uint32_t nvox, PclLeaf* __restrict__ out,
+                                                       PclLeafF* __restrict__ out_f) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
   const uint32_t p0 = vox_start[v], p1 = vox_start[v + 1];
@@ -124,6 +125,13 @@ __global__ void __launch_bounds__(128) k_pclndt_leaves(const float4* __restrict_
   }
   L.n = n;
   out[v] = L;
+  PclLeafF F;
+#pragma unroll
+  for (int a = 0; a < 3; a++) F.mean[a] = L.mean[a];
+#pragma unroll
+  for (int a = 0; a < 9; a++) F.ci[a] = (float)L.icov[a];
+  F.n = n;
+  out_f[v] = F;
 }
 
 __device__ inline void ndt_offset3(int nO, int k, int& ox, int& oy, int& oz) {
@@ -152,6 +160,88 @@ __device__ inline int neighbour_leaf(const TargetView& tg, const PclLeaf* leaves
   return *(const PCM_GLOBAL int32_t*)&L->n >= 6 ? v : -1;   // nr_points >= min_points_per_voxel_  :396
 }
 
+// All neighbour leaves of one point at once.  neighbour_leaf() per cell is a chain of four dependent loads (brick slot, mask word,
+// prefix, leaf header) and a pass that walks 7 cells x 4 points per lane one after the other is nothing but that chain (a lone
+// workgroup needed 110 us for 1 024 points).  Here the brick of the point's own cell is probed once (6 of the 7 / 26 of the 27 cells
+// share it unless the cell lies on a brick face), then every cell's mask word, prefix and leaf header are loaded by straight-line
+// code -- independent loads, in flight together.  v[0 .. count) = the leaves that take part, in the reference's cell order.
+constexpr int kNdtMaxCells = 27;
+__device__ inline int neighbour_leaves(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, int nn, int cx, int cy, int cz, const float (&xt)[3],
+                                       int* __restrict__ v /* LDS, stride 256 */) {
+  const int nk = nn == 0 ? 27 : nn;
+  const int cbx = cx >> kBrickShift, cby = cy >> kBrickShift, cbz = cz >> kBrickShift;
+  int ch = -1;
+  uint32_t cbase = 0;
+  {
+    const uint64_t key = pack_brick(cbx, cby, cbz);
+    uint32_t h = hash_coord(cbx, cby, cbz) & tg.mask;
+    for (;;) {
+      const uint4 s = gload4u(&tg.bricks[h]);
+      const uint64_t sk = slot_key3(s);
+      if (sk == key) { ch = (int)h; cbase = s.z; break; }
+      if (sk == kEmptyKey) break;
+      h = (h + 1) & tg.mask;
+    }
+  }
+  const float r2 = (float)((double)tg.res * (double)tg.res);
+  auto one = [&](int k) {
+    int ox, oy, oz;
+    ndt_offset3(nk, k, ox, oy, oz);
+    const int vx = cx + ox, vy = cy + oy, vz = cz + oz;
+    int h = ch;
+    uint32_t base = cbase;
+    if ((vx >> kBrickShift) != cbx || (vy >> kBrickShift) != cby || (vz >> kBrickShift) != cbz) {   // a cell across a brick face
+      const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
+      const uint64_t key = pack_brick(bx, by, bz);
+      uint32_t hh = hash_coord(bx, by, bz) & tg.mask;
+      h = -1;
+      for (;;) {
+        const uint4 s = gload4u(&tg.bricks[hh]);
+        const uint64_t sk = slot_key3(s);
+        if (sk == key) { h = (int)hh; base = s.z; break; }
+        if (sk == kEmptyKey) break;
+        hh = (hh + 1) & tg.mask;
+      }
+    }
+    const uint32_t li = local_index(vx, vy, vz), w = li >> 5, bit = li & 31;
+    const size_t word = (size_t)(h < 0 ? 0 : h) * 16 + w;   // a valid address either way: the loads below carry no branch
+    const uint32_t m = gload_u(&tg.bmask[word]);
+    const uint32_t pref = gload_u16(&tg.bpref[word]);
+    const bool present = h >= 0 && ((m >> bit) & 1u);
+    const uint32_t leaf = present ? base + pref + (uint32_t)__popc(m & ((1u << bit) - 1u)) : 0u;
+    const PclLeaf* L = leaves + leaf;
+    bool ok;
+    if (nn == 0) {   // KDTREE = radiusSearch(point, resolution) over the centroid cloud
+      float d2 = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 3; a++) { const float df = xt[a] - *(const PCM_GLOBAL float*)&L->centroid[a]; d2 += df * df; }
+      ok = *(const PCM_GLOBAL int32_t*)&L->in_centroids != 0 && d2 < r2;
+    } else if (leaves_f) {
+      ok = *(const PCM_GLOBAL int32_t*)&leaves_f[leaf].n >= 6;   // the line the float pass reads next
+    } else {
+      ok = *(const PCM_GLOBAL int32_t*)&L->n >= 6;   // nr_points >= min_points_per_voxel_  :396
+    }
+    return present && ok ? (int)leaf : -1;
+  };
+  int cnt = 0;
+  if (nk == 7) {
+    int r[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) r[k] = one(k);
+#pragma unroll
+    for (int k = 0; k < 7; k++) if (r[k] >= 0) { v[cnt * 256] = r[k]; cnt++; }
+  } else {
+    for (int k0 = 0; k0 < nk; k0 += 9) {
+      int r[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) r[k] = k0 + k < nk ? one(k0 + k) : -1;
+#pragma unroll
+      for (int k = 0; k < 9; k++) if (r[k] >= 0) { v[cnt * 256] = r[k]; cnt++; }
+    }
+  }
+  return cnt;
+}
+
 __device__ inline double wave_sum3(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -176,8 +266,9 @@ __device__ inline void block_reduce_store(double (&acc)[NS], double* dst) {
 // grid = blocks, block = 256, `per` points per workgroup
 // ---------------------------------------------------------------------------
 template <bool HESS>
-__device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, const NdtOmpParams& P,
-                                               double* __restrict__ partials) {
+__device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per,
+                                               const NdtOmpParams& P,
+                                               double* __restrict__ partials, int* __restrict__ s_leaf /* LDS [kNdtMaxCells][256]: the neighbour leaves of every lane's current point */) {
   const uint32_t begin = blockIdx.x * per;
   uint32_t end = begin + per;
   end = end < n ? end : n;
@@ -185,8 +276,11 @@ __device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLe
 #pragma unroll
   for (int j = 0; j < kNdtSums; j++) acc[j] = 0.0;
   const float gauss_d2 = (float)P.gauss_d2;
+  float4 p_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (begin + threadIdx.x < end) p_next = gload4(src + begin + threadIdx.x);
   for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
-    const float4 p = gload4(src + i);
+    const float4 p = p_next;
+    if (i + 256 < end) p_next = gload4(src + i + 256);   // the lane's next point is under way while this one is worked on
     // pcl::transformPointCloud with final_transformation_ (float)
     float xt[3];
 #pragma unroll
@@ -211,17 +305,23 @@ __device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLe
       for (int j = 0; j < 6; j++) pg[a][j] = (a == j) ? 1.0f : 0.0f;
     }
     pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
-    for (int k = 0; k < (P.num_neighbors == 0 ? 27 : P.num_neighbors); k++) {
-      const int v = neighbour_leaf(tg, leaves, P.num_neighbors, k, cx, cy, cz, xt);
-      if (v < 0) continue;
-      const PclLeaf* L = leaves + v;
+    const int cnt = neighbour_leaves(tg, leaves, leaves_f, P.num_neighbors, cx, cy, cz, xt, s_leaf + threadIdx.x);
+    for (int k = 0; k < cnt; k++) {
+      // the leaf's 64-byte line (mean in double, (float)icov): four 16-byte loads.  (Fetching the next leaf's line while this one is
+      // worked on costs 16 more live registers in a body that is already capped at 255: 55 spilled dwords instead of 15, 2 148 ->
+      // 1 755 registrations/s.)
+      const uint4* Lp = reinterpret_cast<const uint4*>(leaves_f + s_leaf[k * 256 + threadIdx.x]);   // the lane's own words: no barrier
+      const uint4 cu[4] = {gload4u(Lp), gload4u(Lp + 1), gload4u(Lp + 2), gload4u(Lp + 3)};
+      const double mean[3] = {__hiloint2double((int)cu[0].y, (int)cu[0].x), __hiloint2double((int)cu[0].w, (int)cu[0].z), __hiloint2double((int)cu[1].y, (int)cu[1].x)};
+      const float cif[9] = {__uint_as_float(cu[1].z), __uint_as_float(cu[1].w), __uint_as_float(cu[2].x), __uint_as_float(cu[2].y), __uint_as_float(cu[2].z),
+                            __uint_as_float(cu[2].w), __uint_as_float(cu[3].x), __uint_as_float(cu[3].y), __uint_as_float(cu[3].z)};
       float xt4[3], ci[3][3];
 #pragma unroll
-      for (int a = 0; a < 3; a++) xt4[a] = (float)((double)xt[a] - gload_d(&L->mean[a]));
+      for (int a = 0; a < 3; a++) xt4[a] = (float)((double)xt[a] - mean[a]);
 #pragma unroll
       for (int a = 0; a < 3; a++) {
 #pragma unroll
-        for (int b = 0; b < 3; b++) ci[a][b] = (float)gload_d(&L->icov[a * 3 + b]);
+        for (int b = 0; b < 3; b++) ci[a][b] = cif[a * 3 + b];
       }
       // every 4-term float sum of the reference carries a fourth term that is an exact zero (x4[3] = 0, row/column 3 of c_inv4 = 0)
       float xc[3];   // x_trans4 * c_inv4
@@ -274,8 +374,9 @@ __device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLe
 // ---------------------------------------------------------------------------
 // k_pclndt_hessian: computeHessian / updateHessian in double  :498-590
 // ---------------------------------------------------------------------------
-__device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, const NdtOmpParams& P,
-                                           double* __restrict__ partials) {
+__device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per,
+                                           const NdtOmpParams& P,
+                                           double* __restrict__ partials, int* __restrict__ s_leaf) {
   const uint32_t begin = blockIdx.x * per;
   uint32_t end = begin + per;
   end = end < n ? end : n;
@@ -305,10 +406,9 @@ __device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* 
                  vc[3] = {0.0, PCM_DOT3(P.h_ang_d[4]), PCM_DOT3(P.h_ang_d[5])}, vd[3] = {PCM_DOT3(P.h_ang_d[6]), PCM_DOT3(P.h_ang_d[7]), PCM_DOT3(P.h_ang_d[8])},
                  ve[3] = {PCM_DOT3(P.h_ang_d[9]), PCM_DOT3(P.h_ang_d[10]), PCM_DOT3(P.h_ang_d[11])}, vf[3] = {PCM_DOT3(P.h_ang_d[12]), PCM_DOT3(P.h_ang_d[13]), PCM_DOT3(P.h_ang_d[14])};
 #undef PCM_DOT3
-    for (int k = 0; k < (P.num_neighbors == 0 ? 27 : P.num_neighbors); k++) {
-      const int v = neighbour_leaf(tg, leaves, P.num_neighbors, k, cx, cy, cz, xt);
-      if (v < 0) continue;
-      const PclLeaf* L = leaves + v;
+    const int cnt = neighbour_leaves(tg, leaves, leaves_f, P.num_neighbors, cx, cy, cz, xt, s_leaf + threadIdx.x);
+    for (int k = 0; k < cnt; k++) {
+      const PclLeaf* L = leaves + s_leaf[k * 256 + threadIdx.x];
       double xt3[3], ic[9], cxv[3];
 #pragma unroll
       for (int a = 0; a < 3; a++) xt3[a] = (double)xt[a] - gload_d(&L->mean[a]);
@@ -346,13 +446,15 @@ __device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* 
 
 // one object, the parameters in the kernel arguments (pcm_ndt_derivatives, the host-driven solver)
 template <bool HESS>
-__global__ void __launch_bounds__(256, 2) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+__global__ void __launch_bounds__(256, 2) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
                                                             double* __restrict__ partials) {
-  pclndt_derivatives_body<HESS>(tg, leaves, src, n, per, P, partials);
+  __shared__ int s_leaf[kNdtMaxCells * 256];
+  pclndt_derivatives_body<HESS>(tg, leaves, leaves_f, src, n, per, P, partials, s_leaf);
 }
-__global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const PclLeaf* __restrict__ leaves, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+__global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
                                                         double* __restrict__ partials) {
-  pclndt_hessian_body(tg, leaves, src, n, per, P, partials);
+  __shared__ int s_leaf[kNdtMaxCells * 256];
+  pclndt_hessian_body(tg, leaves, leaves_f, src, n, per, P, partials, s_leaf);
 }
 
 // ---------------------------------------------------------------------------
@@ -369,9 +471,10 @@ __global__ void __launch_bounds__(256, 2) k_pclndt_batch_pass(const NdtObject* _
   const int req = ms[blockIdx.y].request;
   if (req < 0 || blockIdx.x >= (uint32_t)ob.nblocks) return;
   const NdtOmpParams& P = ms[blockIdx.y].P;
-  if (req == 0) pclndt_derivatives_body<true>(ob.tg, ob.leaves, ob.src, ob.n, ob.per, P, ob.partials);
-  else if (req == 1) pclndt_derivatives_body<false>(ob.tg, ob.leaves, ob.src, ob.n, ob.per, P, ob.partials);
-  else pclndt_hessian_body(ob.tg, ob.leaves, ob.src, ob.n, ob.per, P, ob.partials);
+  __shared__ int s_leaf[kNdtMaxCells * 256];
+  if (req == 0) pclndt_derivatives_body<true>(ob.tg, ob.leaves, ob.leaves_f, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
+  else if (req == 1) pclndt_derivatives_body<false>(ob.tg, ob.leaves, ob.leaves_f, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
+  else pclndt_hessian_body(ob.tg, ob.leaves, ob.leaves_f, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
 }
 
 // JacobiSVD<Matrix6d>(H, ComputeFullU | ComputeFullV).solve(b) by the whole workgroup: the arithmetic of pcm::svd_solve6 /
@@ -479,15 +582,16 @@ __device__ void svd_solve6_block(const double* H, const double* b, double* x, Sv
   __syncthreads();
 }
 
-// grid = objects, block = 256 (one wave per SIMD: the solver step of thread 0 keeps its 6 x 6 matrices in registers)
-__global__ void __launch_bounds__(256) k_pclndt_batch_step(const NdtObject* __restrict__ objs, ndtomp::NdtMachine* __restrict__ ms, unsigned char* __restrict__ flags_row) {
+// grid = objects, block = 64: ONE wave per object.  The Jacobi rotations of svd_solve6_block use 18 lanes and three barriers each, and a
+// barrier that has to collect four waves costs more than the rotation between two of them (256 threads: 62-85 us per round)
+__global__ void __launch_bounds__(64) k_pclndt_batch_step(const NdtObject* __restrict__ objs, ndtomp::NdtMachine* __restrict__ ms, unsigned char* __restrict__ flags_row) {
   __shared__ double s_grp[16][kNdtStride];
   __shared__ double s_row[kNdtStride];
   const int o = blockIdx.x;
   if (ms[o].request >= 0) {
     const NdtObject ob = objs[o];
     // 16 row groups x 64 columns (48 used), each group summed in row order, then the groups in order: as k_pclndt_reduce
-    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+    for (int idx = threadIdx.x; idx < 1024; idx += 64) {
       const int j = idx & 63, r = idx >> 6;
       if (j < kNdtStride) {
         double v = 0.0;
@@ -588,8 +692,8 @@ TargetView view_of2(const TargetMap& m) {
 
 }  // namespace
 
-int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err) {
-  k_pclndt_leaves<<<(map.num_voxels + 127) / 128, 128, 0, stream>>>(map.pts, map.vox_start, map.num_voxels, d_out);
+int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, PclLeafF* d_out_f, std::string* err) {
+  k_pclndt_leaves<<<(map.num_voxels + 127) / 128, 128, 0, stream>>>(map.pts, map.vox_start, map.num_voxels, d_out, d_out_f);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { *err = std::string("k_pclndt_leaves: ") + hipGetErrorString(e); return PCM_ERR_HIP; }
   return PCM_OK;
@@ -597,12 +701,12 @@ int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out
 
 void launch_pclndt_batch_round(hipStream_t stream, const NdtObject* d_objs, ndtomp::NdtMachine* d_ms, int nobj, int max_blocks, unsigned char* d_flags_row) {
   k_pclndt_batch_pass<<<dim3((unsigned)max_blocks, (unsigned)nobj), 256, 0, stream>>>(d_objs, d_ms);
-  k_pclndt_batch_step<<<nobj, 256, 0, stream>>>(d_objs, d_ms, d_flags_row);
+  k_pclndt_batch_step<<<nobj, 64, 0, stream>>>(d_objs, d_ms, d_flags_row);
 }
 
-NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, double* d_partials) {
+NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, double* d_partials) {
   NdtObject ob{};
-  ob.tg = view_of2(map); ob.leaves = leaves; ob.src = src; ob.n = n;
+  ob.tg = view_of2(map); ob.leaves = leaves; ob.leaves_f = leaves_f; ob.src = src; ob.n = n;
   ob.nblocks = pclndt_workgroups(n, &ob.per);
   ob.partials = d_partials;
   return ob;
@@ -619,13 +723,13 @@ int pclndt_workgroups(uint32_t n, uint32_t* per_out) {
 }
 
 // one derivatives (or Hessian-only) pass; the 48-double result row lands in d_out
-void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
                         double gauss_d3) {
   uint32_t per = 0;
   const int nb = pclndt_workgroups(n, &per);
-  if (pass == 0) k_pclndt_derivatives<true><<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
-  else if (pass == 1) k_pclndt_derivatives<false><<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
-  else if (pass == 2) k_pclndt_hessian<<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, d_partials);
+  if (pass == 0) k_pclndt_derivatives<true><<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, src, n, per, P, d_partials);
+  else if (pass == 1) k_pclndt_derivatives<false><<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, src, n, per, P, d_partials);
+  else if (pass == 2) k_pclndt_hessian<<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, src, n, per, P, d_partials);
   else k_pclndt_score<<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, gauss_d3, d_partials);
   k_pclndt_reduce<<<1, 1024, 0, stream>>>(d_partials, nb, d_out);
 }

@@ -142,6 +142,12 @@ int coord_mode_for(int model) {
   return model == PCM_MODEL_VGICP ? COORD_FLOOR_HALF_D : COORD_FLOOR_HALF;
 }
 
+// PCM_COV_FINE_INDEX=0 switches the fine kNN index of the covariance pass off (A/B measurements)
+bool cov_fine_index_enabled() {
+  static const bool on = [] { const char* e = getenv("PCM_COV_FINE_INDEX"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 size_t num_elements(const pcm_ctx* c) { return c->cfg.model == PCM_MODEL_NDT_D2D ? (size_t)c->srcmap.num_voxels : c->src.n; }
 
 bool is_ndt(int model) { return model == PCM_MODEL_NDT_P2D || model == PCM_MODEL_NDT_D2D; }
@@ -248,11 +254,13 @@ int prepare(pcm_ctx* c) {
     if (!c->pleaf_valid) {
       if (c->pleaf_cap < c->map.num_voxels) {
         if (c->pleaf) hipFree(c->pleaf);
-        c->pleaf = nullptr; c->pleaf_cap = 0;
+        if (c->pleaf_f) hipFree(c->pleaf_f);
+        c->pleaf = nullptr; c->pleaf_f = nullptr; c->pleaf_cap = 0;
         HIPCK(c, hipMalloc(&c->pleaf, sizeof(PclLeaf) * (size_t)c->map.num_voxels));
+        HIPCK(c, hipMalloc(&c->pleaf_f, sizeof(PclLeafF) * (size_t)c->map.num_voxels));
         c->pleaf_cap = c->map.num_voxels;
       }
-      int rc = build_pclndt_leaves(c->stream, c->map, c->pleaf, &c->err);
+      int rc = build_pclndt_leaves(c->stream, c->map, c->pleaf, c->pleaf_f, &c->err);
       if (rc != PCM_OK) return rc;
       c->pleaf_valid = true;
     }
@@ -299,9 +307,15 @@ int prepare(pcm_ctx* c) {
       const int reg_code = c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0);   // + 16: float CUDA-core semantics
       // `if (target_covs_.size() != target_->size()) calculate_covariances(...)`  fast_gicp_impl.hpp:107-109
       const bool given = c->cfg.model != PCM_MODEL_VGICP_CUDA && c->user_cov[1].size() == (size_t)c->map.num_points * 6 && c->map.num_points == c->tgt.n;
-      int rc = given ? upload_covariances(c->stream, c->map, c->user_cov[1].data(), c->tgt_cov, &c->err)
-               : rbf   ? compute_covariances_rbf(c->stream, c->map, c->tgt.d_pts, (uint32_t)c->tgt.n, c->cfg.rbf_kernel_width, c->cfg.rbf_max_dist, c->cfg.regularization, c->tgt_cov, &c->err)
-                       : compute_covariances(c->stream, c->map, c->cfg.k_correspondences, reg_code, c->tgt_cov, &c->err);
+      int rc = PCM_OK;
+      if (given) rc = upload_covariances(c->stream, c->map, c->user_cov[1].data(), c->tgt_cov, &c->err);
+      else if (rbf) rc = compute_covariances_rbf(c->stream, c->map, c->tgt.d_pts, (uint32_t)c->tgt.n, c->cfg.rbf_kernel_width, c->cfg.rbf_max_dist, c->cfg.regularization, c->tgt_cov, &c->err);
+      else {
+        uint32_t n_fine = (uint32_t)c->tgt.n;   // the fine kNN index (see the source cloud below); only when the map holds the whole log
+        const bool fine = cov_fine_index_enabled() && c->map.num_points == c->tgt.n &&
+                          build_target_map(c->stream, c->tgt.d_pts, &n_fine, std::min(c->cfg.voxel_resolution, 0.5f) * 0.125f, mode, false, 0u, &c->covfine, &c->err, true) == PCM_OK;
+        rc = compute_covariances(c->stream, c->map, c->cfg.k_correspondences, reg_code, c->tgt_cov, &c->err, fine ? &c->covfine : nullptr);
+      }
       if (rc != PCM_OK) return rc;
       if (c->cfg.model == PCM_MODEL_VGICP_CUDA) {
         if (c->cvox_cap < c->map.num_voxels) {
@@ -333,9 +347,17 @@ int prepare(pcm_ctx* c) {
         c->src_cov_cap = c->srcmap.num_points;
       }
       const bool given = c->cfg.model != PCM_MODEL_VGICP_CUDA && c->user_cov[0].size() == (size_t)c->srcmap.num_points * 6 && c->srcmap.num_points == c->src.n;   // :104-106
-      int rc = given ? upload_covariances(c->stream, c->srcmap, c->user_cov[0].data(), c->src_cov, &c->err)
-               : rbf   ? compute_covariances_rbf(c->stream, c->srcmap, c->src.d_pts, (uint32_t)c->src.n, c->cfg.rbf_kernel_width, c->cfg.rbf_max_dist, c->cfg.regularization, c->src_cov, &c->err)
-                       : compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0), c->src_cov, &c->err);
+      int rc = PCM_OK;
+      if (given) rc = upload_covariances(c->stream, c->srcmap, c->user_cov[0].data(), c->src_cov, &c->err);
+      else if (rbf) rc = compute_covariances_rbf(c->stream, c->srcmap, c->src.d_pts, (uint32_t)c->src.n, c->cfg.rbf_kernel_width, c->cfg.rbf_max_dist, c->cfg.regularization, c->src_cov, &c->err);
+      else {
+        // a second index of the scan on a grid 8x finer: where one voxel of the search grid holds hundreds of points (a LiDAR's near
+        // field) the 20 nearest lie within a few centimetres, and a candidate box made of 0.5 m voxels is thousands of points
+        uint32_t n_fine = (uint32_t)c->src.n;
+        const bool fine = cov_fine_index_enabled() && build_target_map(c->stream, c->src.d_pts, &n_fine, src_res * 0.125f, mode, false, 0u, &c->covfine, &c->err, true) == PCM_OK;
+        rc = compute_covariances(c->stream, c->srcmap, c->cfg.k_correspondences, c->cfg.regularization + (c->cfg.model == PCM_MODEL_VGICP_CUDA ? 16 : 0), c->src_cov, &c->err,
+                                 fine ? &c->covfine : nullptr);
+      }
       if (rc != PCM_OK) return rc;
       c->src_cov_valid = true;
     }
@@ -761,7 +783,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
 
 // one pclomp NDT pass on the device: launch, read the 48-double row back (pass 0/1: H, g, score; pass 2: H)
 int pclndt_eval(pcm_ctx* c, int pass, const NdtOmpParams& P, ndtomp::Eval* e, double gauss_d3 = 0.0) {
-  launch_pclndt_pass(c->stream, c->map, c->pleaf, c->src.d_pts, (uint32_t)c->src.n, P, pass, c->ndt_partials, c->ndt_out, gauss_d3);
+  launch_pclndt_pass(c->stream, c->map, c->pleaf, c->pleaf_f, c->src.d_pts, (uint32_t)c->src.n, P, pass, c->ndt_partials, c->ndt_out, gauss_d3);
   HIPCK(c, hipGetLastError());
   HIPCK(c, hipMemcpyAsync(c->ndt_out_host, c->ndt_out, sizeof(double) * 48, hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
@@ -841,7 +863,7 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   int max_blocks = 1;
   for (int i = 0; i < n; i++) {
     pcm_ctx* c = ctxs[i];
-    w.h_objs[i] = make_ndt_object(c->map, c->pleaf, c->src.d_pts, (uint32_t)c->src.n, c->ndt_partials);
+    w.h_objs[i] = make_ndt_object(c->map, c->pleaf, c->pleaf_f, c->src.d_pts, (uint32_t)c->src.n, c->ndt_partials);
     max_blocks = std::max(max_blocks, (int)w.h_objs[i].nblocks);
     ndtomp::ndt_machine_start(w.h_ms[i], guesses + 16 * (size_t)i, (double)c->cfg.ndt_step_size, c->cfg.translation_eps, (double)c->cfg.ndt_outlier_ratio,
                               c->cfg.voxel_resolution, c->cfg.max_iterations, c->cfg.num_neighbors);
@@ -1023,6 +1045,7 @@ void pcm_destroy(pcm_ctx* c) {
     c->ndt_ws = nullptr;
     c->map.release();
     c->srcmap.release();
+    c->covfine.release();
     if (c->corr) hipFree(c->corr);
     if (c->src_cov) hipFree(c->src_cov);
     if (c->tgt_cov) hipFree(c->tgt_cov);
@@ -1030,6 +1053,7 @@ void pcm_destroy(pcm_ctx* c) {
     if (c->cvox) hipFree(c->cvox);
     if (c->maha) hipFree(c->maha);
     if (c->pleaf) hipFree(c->pleaf);
+    if (c->pleaf_f) hipFree(c->pleaf_f);
     if (c->pre_arena) hipFree(c->pre_arena);
     if (c->bfgs) hipFree(c->bfgs);
     if (c->bfgs_idx) hipFree(c->bfgs_idx);

@@ -119,6 +119,14 @@ struct PclLeaf {
   float pad;
 };
 static_assert(sizeof(PclLeaf) == 120, "PclLeaf must be 120 bytes");
+// What the float passes of computeDerivatives read of a leaf, in ONE 64-byte line: the mean (double: x_trans = x - mean is taken in
+// double and cast) and (float)icov -- the cast updateDerivatives applies at every use (ndt_omp_impl.hpp:469) made once, same bits.
+struct PclLeafF {
+  double mean[3];
+  float ci[9];
+  int32_t n;   // = PclLeaf::n
+};
+static_assert(sizeof(PclLeafF) == 64, "PclLeafF must be one 64-byte line");
 
 // Explicit global-address-space accessors.  Pointers that reach a kernel through a
 // descriptor struct are generic to the compiler; a generic (flat) load counts on
@@ -213,6 +221,7 @@ struct PairDesc {
 struct NdtObject {
   TargetView tg;
   const PclLeaf* leaves;
+  const PclLeafF* leaves_f;
   const float4* src;
   uint32_t n, per;        // scan points, points per workgroup
   int32_t nblocks, pad;   // workgroup rows of a pass

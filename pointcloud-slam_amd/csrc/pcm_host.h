@@ -36,6 +36,7 @@ struct TargetMap {   // layout: pcm_device.h
   float4* pts = nullptr;
   GaussVoxel* gvox = nullptr;   // NDT models
   uint32_t* order = nullptr;    // input index of every map point (kept on request: GICP covariances are reported in input order)
+  size_t order_cap = 0;
   // the sorted index of the point log the tables were built from (key, log position), kept for the next batch of a sliding map
   // (voxel_hash.hip: merged, not re-sorted), and its double buffer
   uint64_t *keys_s = nullptr, *keys_t = nullptr;
@@ -69,7 +70,7 @@ struct TargetMap {   // layout: pcm_device.h
     h_ctr = nullptr;
     gvox = nullptr; order = nullptr; keys_s = keys_t = nullptr; idx_s = idx_t = nullptr;
     bricks = nullptr; bmask = nullptr; bpref = nullptr; vox_start = nullptr; pts = nullptr;
-    keys_cap = keys_t_cap = idx_cap = idx_t_cap = vox_cap = pts_cap = 0; bricks_cap = 0; index_n = 0;
+    keys_cap = keys_t_cap = idx_cap = idx_t_cap = vox_cap = pts_cap = order_cap = 0; bricks_cap = 0; index_n = 0;
     cap = num_voxels = num_bricks = num_points = 0; max_voxel_points = 0; valid = false;
   }
 };
@@ -139,20 +140,20 @@ void launch_ndt(hipStream_t stream, const PairDesc* d_descs, const PairState* d_
 void launch_fitness(hipStream_t stream, const TargetView& tg, int coord_mode, const float4* src, uint32_t n, const float* T, double max_range, double* d_out);
 void launch_gicp(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool vgicp, bool trial);
 // gicp.hip: kNN covariances of every point of a built map (map order, 6 doubles each); VGICP voxel distributions
-int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err);
+int compute_covariances(hipStream_t stream, const TargetMap& map, int k, int regularization, double* d_out, std::string* err, const TargetMap* fine = nullptr);
 // RBF-kernel covariances of the CUDA core (GPU_RBF_KERNEL): map order out, sums over the input order
 int compute_covariances_rbf(hipStream_t stream, const TargetMap& map, const float4* d_input_order, uint32_t n, double kernel_width, double max_dist, int regularization, double* d_out,
                             std::string* err);
 int build_vgicp_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, int mode, VgVoxel* d_out, std::string* err);
 int build_vgc_voxels(hipStream_t stream, const TargetMap& map, const double* d_cov, VgcVoxel* d_out, std::string* err);
 // pclndt.hip: pclomp NDT leaves and derivative passes (pass 0: score+gradient+Hessian, 1: score+gradient, 2: double Hessian only)
-int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, std::string* err);
+int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, PclLeafF* d_out_f, std::string* err);
 int pclndt_workgroups(uint32_t n, uint32_t* per_out);
 namespace ndtomp { struct NdtMachine; }
-NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, double* d_partials);
+NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, double* d_partials);
 // one round of a batched pclomp NDT registration: the pass every live object waits for, then the sums + solver step per object
 void launch_pclndt_batch_round(hipStream_t stream, const NdtObject* d_objs, ndtomp::NdtMachine* d_ms, int nobj, int max_blocks, unsigned char* d_flags_row);
-void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
                         double gauss_d3 = 0.0);   // pass 3: calculateScore (needs gauss_d3)
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations, int window, unsigned int* d_queue);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);
@@ -167,6 +168,7 @@ struct pcm_ctx {
   pcm::Cloud src, tgt;
   pcm::TargetMap map;
   pcm::TargetMap srcmap;          // NDT D2D: the source's own voxel distributions
+  pcm::TargetMap covfine;         // GICP: the cloud whose covariances are being computed, on a grid 8x finer (kNN index of dense neighbourhoods only)
   int32_t* corr = nullptr;        // NDT: matched voxel per (element, offset) of the last linearize
   size_t corr_cap = 0;
   // GICP / VGICP: per-point covariances in MAP order (the source elements are srcmap.pts), voxel distributions, Mahalanobis cache
@@ -184,6 +186,7 @@ struct pcm_ctx {
   size_t maha_cap = 0;
   // pclomp NDT: leaf payload of the map, partial rows, result row (device + pinned host)
   pcm::PclLeaf* pleaf = nullptr;
+  pcm::PclLeafF* pleaf_f = nullptr;   // the float passes' 64-byte view of the same leaves
   size_t pleaf_cap = 0;
   bool pleaf_valid = false;
   double* ndt_partials = nullptr;

@@ -566,7 +566,11 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     CK(hipGetLastError());
     CK(hipMemcpyAsync(map->h_ctr, d_flags, kCtrInts * sizeof(int), hipMemcpyDeviceToHost, stream));   // complete at the synchronize below
     if (map->gvox) { (void)hipStreamSynchronize(stream); hipFree(map->gvox); map->gvox = nullptr; }
-    if (map->order) { (void)hipStreamSynchronize(stream); hipFree(map->order); map->order = nullptr; }
+    if (map->order && !keep_order) { (void)hipStreamSynchronize(stream); hipFree(map->order); map->order = nullptr; map->order_cap = 0; }
+    if (keep_order) {   // a persistent copy of the input index of every map point (capacity-managed: a scan per registration re-uses it)
+      RC(grow(&map->order, &map->order_cap, (size_t)n, 0, stream, err, "order"));
+      CK(hipMemcpyAsync(map->order, map->idx_s, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    }
     if (want_gauss) {
       CK(hipMalloc(&map->gvox, sizeof(GaussVoxel) * ((size_t)nvox + 1)));
       k_gauss_voxels<<<cdiv(nvox, 128), 128, 0, stream>>>(map->pts, map->vox_start, nvox, map->gvox);
@@ -574,11 +578,6 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
     }
     CK(hipStreamSynchronize(stream));
     map->max_voxel_points = (uint32_t)map->h_ctr[2];
-    if (keep_order) {   // a persistent copy of the input index of every map point
-      CK(hipMalloc(&map->order, sizeof(uint32_t) * (size_t)n));
-      CK(hipMemcpyAsync(map->order, map->idx_s, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, stream));
-      CK(hipStreamSynchronize(stream));
-    }
     map->cap = cap;
     map->num_voxels = nvox;
     map->num_bricks = nbricks;

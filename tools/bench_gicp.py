@@ -10,14 +10,20 @@ ap.add_argument("--scan", type=int, default=100_000)
 ap.add_argument("--pairs", type=int, default=8)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--cpu", type=int, default=1)
+ap.add_argument("--models", default="GICP,GICP_unbounded,VGICP_direct1,VGICP_direct7")
+ap.add_argument("--lib", default="", help="A/B: load this build of the library")
 a = ap.parse_args()
 synth = importlib.import_module("pointcloud-slam_amd.synth")
 pairs = [synth.make_pair(i, a.scan, a.map) for i in range(a.pairs)]
 import torch
 import pointcloud_slam_amd as pcm
+if a.lib:
+    pcm.capi.library_path = lambda: os.path.abspath(a.lib)
 out = {}
 for name, cls, kw in (("GICP", pcm.GicpRegistration, {"max_corr_dist": 1.0}), ("GICP_unbounded", pcm.GicpRegistration, {}),
                       ("VGICP_direct1", pcm.VgicpRegistration, {}), ("VGICP_direct7", pcm.VgicpRegistration, {"num_neighbors": 7})):
+    if name not in a.models.split(","):
+        continue
     regs = []
     d_scans = [torch.from_numpy(p.scan).cuda() for p in pairs]
     torch.cuda.synchronize(); t0 = time.perf_counter()
