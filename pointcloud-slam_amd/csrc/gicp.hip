@@ -414,7 +414,19 @@ __global__ void __launch_bounds__(256, KCAP <= 20 ? 3 : 1) k_covariances(TargetV
           __syncthreads();
           COV_T(25);
           if (!gexact) {
-            for (uint32_t j = wave; j < nst; j += 4) {
+            // four staged points per trip, all four LDS reads under way before the first is used: one point per trip is one LDS
+            // round trip per point (the scan was 120 of a workgroup's 210 us, ~500 cycles per point and wave).
+            // (Queueing the candidates that pass a lane's threshold per lane and running the shift network on full queues only --
+            // every lane inserting in the same turn -- was tried: 131 -> 161 us, the network is not what the scan waits for.)
+            uint32_t j = wave;
+            for (; j + 12 < nst; j += 16) {
+              const float4 c0 = st[j], c1 = st[j + 4], c2 = st[j + 8], c3 = st[j + 12];
+              { const float ex = c0.x - q[0], ey = c0.y - q[1], ez = c0.z - q[2]; visit(__float_as_uint(c0.w), ex * ex + ey * ey + ez * ez); }
+              { const float ex = c1.x - q[0], ey = c1.y - q[1], ez = c1.z - q[2]; visit(__float_as_uint(c1.w), ex * ex + ey * ey + ez * ez); }
+              { const float ex = c2.x - q[0], ey = c2.y - q[1], ez = c2.z - q[2]; visit(__float_as_uint(c2.w), ex * ex + ey * ey + ez * ez); }
+              { const float ex = c3.x - q[0], ey = c3.y - q[1], ez = c3.z - q[2]; visit(__float_as_uint(c3.w), ex * ex + ey * ey + ez * ez); }
+            }
+            for (; j < nst; j += 4) {
               const float4 c = st[j];
               const float ex = c.x - q[0], ey = c.y - q[1], ez = c.z - q[2];
               visit(__float_as_uint(c.w), ex * ex + ey * ey + ez * ez);

@@ -142,9 +142,16 @@ int coord_mode_for(int model) {
   return model == PCM_MODEL_VGICP ? COORD_FLOOR_HALF_D : COORD_FLOOR_HALF;
 }
 
-// PCM_COV_FINE_INDEX=0 switches the fine kNN index of the covariance pass off (A/B measurements)
+// PCM_COV_FINE_INDEX=1 switches the fine kNN index of the covariance pass on (measured: fewer candidates, but the second index
+// build and its query order cost more than they save on the bench scans -- DESIGN section 3)
 bool cov_fine_index_enabled() {
-  static const bool on = [] { const char* e = getenv("PCM_COV_FINE_INDEX"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = getenv("PCM_COV_FINE_INDEX"); return e && e[0] == '1'; }();
+  return on;
+}
+
+// PCM_COV_SUBSORT=0: the scan's kNN index keeps input order inside its voxels (A/B measurements)
+bool cov_subsort_enabled() {
+  static const bool on = [] { const char* e = getenv("PCM_COV_SUBSORT"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -293,7 +300,8 @@ int prepare(pcm_ctx* c) {
     const float src_res = std::min(c->cfg.voxel_resolution, 0.5f);
     if (!c->srcmap.valid || c->srcmap.res != src_res || c->srcmap.coord_mode != mode) {
       uint32_t n_src = (uint32_t)c->src.n;
-      int rc = build_target_map(c->stream, c->src.d_pts, &n_src, src_res, mode, false, 0u, &c->srcmap, &c->err, true);
+      // sub-voxel order: 64 consecutive points of the brick-major scan are one patch (k_covariances; k_gicp reads it point by point)
+      int rc = build_target_map(c->stream, c->src.d_pts, &n_src, src_res, mode, false, 0u, &c->srcmap, &c->err, true, 0u, nullptr, cov_subsort_enabled());
       if (rc != PCM_OK) return rc;
       c->src_cov_valid = false;
     }
@@ -893,7 +901,8 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   // host-side waiting, so it is made for small batches only.
   size_t total_points = 0;
   for (int i = 0; i < n; i++) total_points += ctxs[i]->src.n;
-  const int ngroups = total_points <= 1000000 ? std::min(n, 4) : 1;
+  int ngroups = total_points <= 1000000 ? std::min(n, 4) : 1;
+  if (const char* e = getenv("PCM_NDT_GROUPS")) ngroups = std::max(1, std::min(n, atoi(e)));   // measurements only
   std::vector<Group> groups((size_t)ngroups);
   for (int g = 0; g < ngroups; g++) {
     Group& G = groups[(size_t)g];

@@ -77,7 +77,7 @@ struct TargetMap {   // layout: pcm_device.h
 
 // n_indexed > 0: the first n_indexed points of the log are what map->keys_s / idx_s index; only the points behind them are new
 int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
-                     std::string* err, bool keep_order = false, uint32_t n_indexed = 0, uint32_t* lru_hazards = nullptr);
+                     std::string* err, bool keep_order = false, uint32_t n_indexed = 0, uint32_t* lru_hazards = nullptr, bool subsort = false);
 int load_points_to_device(hipStream_t stream, const void* points, size_t n, size_t stride, int memory, uint32_t seq0, float4* d_out, std::string* err);
 // batched scan re-ordering (voxel_hash.hip)
 struct SortJob {

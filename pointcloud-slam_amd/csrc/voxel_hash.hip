@@ -345,6 +345,21 @@ __global__ void k_voxel_firsts(const uint32_t* __restrict__ vflag, const uint32_
   if (i < n && vflag[i]) vox_first[vrank[i]] = i;
 }
 
+// Sub-voxel order (build_target_map(..., subsort)): a voxel's points are one run of the sorted index in INPUT order, i.e. scattered
+// all over the voxel; a consumer that works on 64 consecutive map points at a time (k_covariances) wants them to be one small patch
+// instead.  Key = (voxel rank, Morton code of the point's cell on a grid 8x finer); one more radix sort permutes the index inside
+// the voxels only (the voxel keys stay where they are).  Only for maps whose within-voxel order nothing else depends on.
+__device__ inline uint32_t spread3(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); }
+__global__ void k_subvoxel_keys(const float4* __restrict__ pts, const uint32_t* __restrict__ idx_s, const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vrank, uint32_t n, float inv_res,
+                                uint64_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[idx_s[i]];
+  const int cx = (int)floorf(p.x * inv_res * 8.f), cy = (int)floorf(p.y * inv_res * 8.f), cz = (int)floorf(p.z * inv_res * 8.f);
+  const uint32_t m = spread3((uint32_t)cx & 7u) | (spread3((uint32_t)cy & 7u) << 1) | (spread3((uint32_t)cz & 7u) << 2);
+  keys[i] = ((uint64_t)(vrank[i] + vflag[i] - 1u) << 9) | m;   // vrank is the EXCLUSIVE scan of the head flags: a head holds its voxel's index, the rest of the run one more
+}
+
 // Scratch of one build: a sliding map keeps a grow-only arena (an update then makes no allocation call at all: two dozen
 // hipMallocAsync / hipFreeAsync pairs were a third of an update's wall time); any other build takes from the stream-ordered pool.
 struct BuildScratch {
@@ -385,7 +400,7 @@ static int grow(T** p, size_t* cap, size_t need, size_t keep_elems, hipStream_t 
 // map->keys_s / idx_s index -- merge the points appended since.  Host syncs: voxel / brick counts (array sizes), once more after
 // an eviction.
 int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float res, int coord_mode, bool want_gauss, uint32_t capacity_voxels, TargetMap* map,
-                     std::string* err, bool keep_order, uint32_t n_indexed, uint32_t* lru_hazards) {
+                     std::string* err, bool keep_order, uint32_t n_indexed, uint32_t* lru_hazards, bool subsort) {
   uint32_t n = *n_inout;
   if (n == 0) { map->release(); *err = "empty target cloud"; return PCM_ERR_NO_INPUT; }
   const bool incremental = n_indexed > 0 && n_indexed <= n && map->keys_s && map->idx_s && map->index_n == n_indexed && map->res == res && map->coord_mode == coord_mode && !want_gauss && !keep_order;
@@ -477,6 +492,21 @@ int build_target_map(hipStream_t stream, float4* d_pts, uint32_t* n_inout, float
       return rc;
     };
     RC(heads(n));
+    if (subsort && !incremental) {   // permute the index inside the voxels (the heads and ranks above stay valid: same keys at the same places)
+      uint64_t *k2 = nullptr, *k2s = nullptr;
+      void* tmp5 = nullptr;
+      size_t tmp5_bytes = 0;
+      int bits = 9;
+      while (bits < 41 && (1ull << (bits - 9)) < (unsigned long long)nvox) bits++;
+      CK(sc.get(reinterpret_cast<void**>(&k2), sizeof(uint64_t) * n, stream));
+      CK(sc.get(reinterpret_cast<void**>(&k2s), sizeof(uint64_t) * n, stream));
+      k_subvoxel_keys<<<cdiv(n, 256), 256, 0, stream>>>(d_pts, map->idx_s, vflag, vrank, n, inv_res, k2);
+      CK(hipGetLastError());
+      CK(rocprim::radix_sort_pairs(nullptr, tmp5_bytes, k2, k2s, map->idx_s, map->idx_t, n, 0, bits, stream));
+      CK(sc.get(&tmp5, tmp5_bytes, stream));
+      CK(rocprim::radix_sort_pairs(tmp5, tmp5_bytes, k2, k2s, map->idx_s, map->idx_t, n, 0, bits, stream));
+      std::swap(map->idx_s, map->idx_t); std::swap(map->idx_cap, map->idx_t_cap);
+    }
     if (capacity_voxels > 1 && nvox > capacity_voxels - 1) {
       // ---- 3. LRU eviction: keep the (capacity - 1) most recently touched voxels; log and index are compacted in place ------
       const uint32_t keep = capacity_voxels - 1;

@@ -1,15 +1,11 @@
 #!/bin/bash
-# Final checks of a binary in one call: __graft_entry__.smoke, the GPU suite, the default bench line, the rocprofv3 kernel
+# Final checks of a binary, part B (part A = r03_final_tests.sh): the default bench line, the rocprofv3 kernel
 # summaries (default two-slot schedule, single stream), the SQ counter pass behind roofline.achieved (profiles/pmc_valu.json) and the
 # FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic (profiles/pmc_traffic.json).  Outputs under gpurun_out/r03final.
 set -e
 export TMPDIR=/tmp
 O=gpurun_out/r03final
 mkdir -p $O
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
-tail -1 $O/smoke.log
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
-tail -2 $O/gpu_tests.log
 python tools/gen_cache.py --pairs 64 > $O/gen.log 2>&1
 B="python3 bench.py --cpu-seconds 0 --pairs-cache /tmp/pcm_pairs.npz"
 K="k_linearize<false, false"
