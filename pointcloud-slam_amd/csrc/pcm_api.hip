@@ -896,12 +896,12 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   // objects have finished.  At most two rounds of a group are in flight (the host confirms a round's status bytes before it queues
   // the one after the next); a group whose objects have all finished sees that one round late and stops.
   struct Group { int lo, hi, max_blocks, launched, confirmed; bool done; hipStream_t st; };
-  // Measured at config 4 (100k-point scans): 8 objects -- four groups of two 1 081 registrations/s, one group 898; 32 objects -- four
-  // groups 1 814, one group 2 058; 16 objects -- four groups 897, one group 1 406: with the device busy a split only adds launches and
-  // host-side waiting, so it is made for small batches only.
+  // Measured at config 4 (100k-point scans, tools/r03_scaling.sh): 8 objects -- four groups 1 175 registrations/s, two 1 122; 16 objects --
+  // one group 1 548, two 1 781, four 953; 32 objects -- one 2 340, two 2 753, three 2 217, four 1 990: one group's solver step and the
+  // ragged end of its pass overlap the other's pass; more groups only add launches and host-side waiting.
   size_t total_points = 0;
   for (int i = 0; i < n; i++) total_points += ctxs[i]->src.n;
-  int ngroups = total_points <= 1000000 ? std::min(n, 4) : 1;
+  int ngroups = total_points <= 1000000 ? std::min(n, 4) : std::min(n, 2);
   if (const char* e = getenv("PCM_NDT_GROUPS")) ngroups = std::max(1, std::min(n, atoi(e)));   // measurements only
   std::vector<Group> groups((size_t)ngroups);
   for (int g = 0; g < ngroups; g++) {
