@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--stagger", type=float, default=0.5, help="start offset between the pipeline slots, in units of one warm pass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured path); gloo only to rehearse the N>1 control flow with several ranks sharing one GPU")
+    ap.add_argument("--collectives-at-one", type=int, default=0,
+                    help="1: at N=1 still create the process group and run the per-pass all-gather (world size 1): executes the RCCL path of N>1 on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +172,10 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
 
+    use_dist = world >= 2 or bool(args.collectives_at_one)   # N>1, or the same code path at world size 1
+    if use_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
     cfg = dict(optimizer=args.optimizer, voxel_resolution=0.5, num_neighbors=27, max_iterations=args.max_iterations)
 
     # ---- inputs (host), before the GPU is touched so that fork() is safe -------------------------
@@ -195,7 +201,7 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl")   # backend "nccl" is RCCL on ROCm; communicators are created by the warm-up collectives below
         else:
@@ -227,7 +233,7 @@ def main():
     rec = ctypes.sizeof(capi.PcmResult)
     # result blocks: split -> one block of n_local records, slot j owns its slice; rotate -> one block of n_local records per slot
     d_results = torch.zeros(n_sets * n_local * rec, dtype=torch.uint8, device=dev)
-    d_gather = torch.zeros(n_sets * world * n_local * rec, dtype=torch.uint8, device=dev) if world > 1 else None
+    d_gather = torch.zeros(n_sets * world * n_local * rec, dtype=torch.uint8, device=dev) if use_dist else None
 
     # ---- S batches in flight per GPU, each driven by its own host thread on its own stream ----
     lead = [reg_sets[j][0] if rotate else regs[groups[j][0]] for j in range(S)]    # the object whose stream / statistics a slot's batches use
@@ -244,9 +250,9 @@ def main():
     # gathers as they finished: rank A could enqueue slot 0 then 1 while rank B enqueued 1 then 0, the documented way to hang
     # concurrent RCCL communicators.)  The slots keep overlapping their COMPUTE; a slot only waits for the gather of its previous
     # step before it overwrites that step's result block.
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    bar_kw = {"device_ids": [dev_index]} if (world > 1 and args.backend == "nccl") else {}
-    if world > 1:   # create the communicator before the timed region
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    bar_kw = {"device_ids": [dev_index]} if (use_dist and args.backend == "nccl") else {}
+    if use_dist:   # create the communicator before the timed region
         dist.all_reduce(torch.zeros(1, device=dev))
         torch.cuda.synchronize()
 
@@ -287,15 +293,15 @@ def main():
             sys.stderr.write("rank %d: %r -- aborting the job\n" % (rank, exc))
             sys.stderr.flush()
             os._exit(13)
-        kw = dict(on_thread_start=lambda: torch.cuda.set_device(dev_index), on_error=fail_fast if world > 1 else None)
+        kw = dict(on_thread_start=lambda: torch.cuda.set_device(dev_index), on_error=fail_fast if use_dist else None)
         if rotate:
-            return sharding.run_rotating_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s, **kw)
-        last = sharding.run_pipelined_steps(k, S, sub_step, gather_slot if world > 1 else None, stagger_s, **kw)
+            return sharding.run_rotating_steps(k, S, sub_step, gather_slot if use_dist else None, stagger_s, **kw)
+        last = sharding.run_pipelined_steps(k, S, sub_step, gather_slot if use_dist else None, stagger_s, **kw)
         return [r for grp in last for r in grp]
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier(**bar_kw)
             torch.cuda.synchronize()
 
@@ -330,7 +336,7 @@ def main():
         lead[j].set_profiling(0)
 
     t = torch.tensor([elapsed, t_cold], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, t_cold = float(t[0]), float(t[1])
 
@@ -360,7 +366,7 @@ def main():
     probes = sc["slots_probed"] / max(1, sc["point_passes"])
 
     gathered_ok = None
-    if world > 1:   # untimed check of the exchange: own block round-trips, every rank's poses arrived
+    if use_dist:   # untimed check of the exchange: own block round-trips, every rank's poses arrived
         allrec = d_gather.view(n_sets, world, n_local * rec)[0]
         if not torch.equal(allrec[rank], d_results[:n_local * rec]):
             raise SystemExit("rank %d: gathered block differs from the local results" % rank)
@@ -426,7 +432,7 @@ def main():
                                    % (args.scan_points, args.map_points, args.optimizer, n_local),
                        "pairs_per_gpu": n_local, "batches_in_flight": S, "schedule": args.schedule, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
                        "flags": args.flags, "search_kernel": "k_linearize_counted" if (args.flags & 8) else "k_linearize",
-                       "target_reuse": True, "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
+                       "target_reuse": True, "collectives_executed": bool(use_dist), "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},
             "roofline": roof,
@@ -438,7 +444,7 @@ def main():
             out["config"].update(full_size_parity(res, oracle_results))   # untimed: the timed GPU poses against the oracle's, full size
             one, _ = cpu_baseline(pairs[:3], cfg, min(15.0, args.cpu_seconds), threads=1)
             out["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
-    if world > 1:
+    if use_dist:
         dist.barrier(**bar_kw)
         dist.destroy_process_group()
     if rank == 0:

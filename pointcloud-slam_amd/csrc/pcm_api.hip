@@ -901,7 +901,9 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   // ragged end of its pass overlap the other's pass; more groups only add launches and host-side waiting.
   size_t total_points = 0;
   for (int i = 0; i < n; i++) total_points += ctxs[i]->src.n;
-  int ngroups = total_points <= 1000000 ? std::min(n, 4) : std::min(n, 2);
+  // (the 27-cell searches -- KDTREE, DIRECT26 -- lose with two groups: 1 570 -> 1 213 at 32 scans; their pass keeps the device busy alone)
+  const bool wide = c0->cfg.num_neighbors == 0 || c0->cfg.num_neighbors > 7;
+  int ngroups = total_points <= 1000000 ? std::min(n, 4) : (wide ? 1 : std::min(n, 2));
   if (const char* e = getenv("PCM_NDT_GROUPS")) ngroups = std::max(1, std::min(n, atoi(e)));   // measurements only
   std::vector<Group> groups((size_t)ngroups);
   for (int g = 0; g < ngroups; g++) {
