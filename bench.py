@@ -314,6 +314,8 @@ def main():
     fence()
     t_cold = (time.perf_counter() - t0) / per
 
+    run_steps(per)   # second registration against every target: the per-voxel candidate lists are built here (untimed, not part of t_warm)
+    fence()
     t0 = time.perf_counter()
     for _ in range(max(1, args.warmup - 1)):
         run_steps(per)
@@ -396,7 +398,9 @@ def main():
     traffic_p, traffic_ok = load_profile("pmc_traffic.json", workload_key)
     valu_per_wave = float(valu["valu_per_wave"]) if valu else None
     b_pi = POINT_BYTES + cfg["num_neighbors"] * SLOT_BYTES + kbar * POINT_BYTES
-    roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GIPS, "kernel": "k_linearize_counted" if (args.flags & 8) else "k_linearize",
+    # the kernel the timed passes run (pcm_amd.h PCM_FLAG_*): candidate lists by default from a target's second registration on
+    search_kernel = "k_linearize_counted" if (args.flags & 8) else ("k_linearize" if (args.flags & (64 | 32 | 2 | 1)) else "k_linearize_lists")
+    roof = {"bound": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GIPS, "kernel": search_kernel,
             "achieved": None, "frac": None, "traffic": None}
     if valu_per_wave:
         ach = valu_per_wave * waves_per_step / (ms_per_step * 1e-3) / 1e9
@@ -431,7 +435,7 @@ def main():
                                    " (configs[2] = the same pairs at 32 per GPU over 8 GPUs: --gpus 8 --pairs-per-gpu 32)"
                                    % (args.scan_points, args.map_points, args.optimizer, n_local),
                        "pairs_per_gpu": n_local, "batches_in_flight": S, "schedule": args.schedule, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
-                       "flags": args.flags, "search_kernel": "k_linearize_counted" if (args.flags & 8) else "k_linearize",
+                       "flags": args.flags, "search_kernel": search_kernel,
                        "target_reuse": True, "collectives_executed": bool(use_dist), "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},

@@ -96,7 +96,7 @@ typedef struct pcm_config {
   int32_t k_correspondences;     /* 20  impl/fast_gicp_impl.hpp:16 */
   int32_t regularization;        /* pcm_regularization; PLANE  impl/fast_gicp_impl.hpp:20 */
   int32_t sort_source;           /* 1: order the scan along a Morton curve on device (speed only; default 1) */
-  int32_t flags;                 /* PCM_FLAG_*: bits 0-1 and 3 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics, bit 5 the neighbour row order */
+  int32_t flags;                 /* PCM_FLAG_*: bits 0-1, 3, 4 and 6 speed / debugging only (never change a result), bit 2 selects the ObsModel semantics, bit 5 the neighbour row order */
   int32_t map_capacity;          /* sliding map: max voxels kept, LRU beyond (IVox capacity_ 1000000, ivox3d.h:57); 0 = unlimited */
   float ndt_step_size;           /* pclomp NDT: step_size_ 0.1 (maximum More-Thuente step)  ndt_omp_impl.hpp:48 */
   float ndt_outlier_ratio;       /* pclomp NDT: outlier_ratio_ 0.55  ndt_omp_impl.hpp:48 */
@@ -124,6 +124,13 @@ typedef struct pcm_config {
 #define PCM_FLAG_COUNTED_SEARCH 8    /* P2PLANE: k_linearize_counted (linearize_counted.hip: voxel point counts in the LDS cell grid, four candidates per cell and
                                      * trip, rolled cell loop, DPP reductions) instead of k_linearize; same neighbour lists, planes and sums bit for bit.
                                      * 14 % fewer vector instructions and a third of the code, measured 12 % SLOWER (profiles/r03_bench_ab_*.json): A/B switch */
+#define PCM_FLAG_NEIGHBOUR_LISTS 16   /* P2PLANE against a static target: the linearize pass runs on per-voxel candidate lists -- for every voxel a query can fall
+                                       * into, the points of its neighbour voxels in the reference's visit order, contiguous (27 x 16 B per map point), built
+                                       * on the device (neighbour_lists.hip) -- instead of re-deriving the candidates per pass through LDS.  Same candidates
+                                       * in the same order: bit-identical results, 1.8x the kernel speed.  DEFAULT: the lists are built when a target is
+                                       * registered against the second time; this flag builds them with the map (first registration already).  Never for a
+                                       * target that has grown (pcm_target_insert / pcm_map_incremental), the LIO model, or next to another kernel flag. */
+#define PCM_FLAG_NO_NEIGHBOUR_LISTS 64 /* never build them: the tile kernel (kernels.hip) serves every pass */
 #define PCM_FLAG_REFERENCE_KNN_ORDER 32
 /* P2PLANE align / linearize: hand esti_plane its neighbours in the row order the reference's IVox::GetClosestPoint leaves -- the
  * order of libstdc++'s std::nth_element (jueying_lio/include/ivox3d/ivox3d.h:173-178, ivox3d_node.hpp:176-181) -- instead of

@@ -22,6 +22,8 @@ PCM_OK = 0
 PCM_FLAG_NO_LDS_STAGING = 1
 PCM_FLAG_FUSED_STEP = 2
 PCM_FLAG_COUNTED_SEARCH = 8           # k_linearize_counted instead of k_linearize (A/B; same results, measured slower)
+PCM_FLAG_NEIGHBOUR_LISTS = 16           # static targets: per-voxel candidate lists built with the map (default: from the 2nd registration on), same results
+PCM_FLAG_NO_NEIGHBOUR_LISTS = 64        # never: the tile kernel serves every pass
 PCM_FLAG_REFERENCE_KNN_ORDER = 32      # neighbours in the order of libstdc++'s std::nth_element (the reference's), slower kernel
 PCM_FLAG_LIO_REFERENCE_SEMANTICS = 4   # pcm_obs_model keeps LaserMapping's per-point members across calls and scans
 PCM_ERR_NOT_CONVERGED = -6

@@ -233,6 +233,17 @@ int set_cloud(pcm_ctx* c, Cloud* cl, const void* points, size_t n, size_t stride
   return PCM_OK;
 }
 
+// P2PLANE against a static target: the linearize pass runs on per-voxel candidate lists (neighbour_lists.hip).  The lists cost a
+// build (several ms and 27 x 16 B per map point), so by default they are made when a target is registered against the SECOND time
+// (the reference's own protocols re-use a target: fast_gicp/src/align.cpp:51-104, jueying_slam's localization against one global map);
+// PCM_FLAG_NEIGHBOUR_LISTS builds them with the map, PCM_FLAG_NO_NEIGHBOUR_LISTS never.  A target that grows through
+// pcm_target_insert / pcm_map_incremental would rebuild them with every batch: it keeps the tile kernel.
+bool uses_neighbour_lists(const pcm_ctx* c) {
+  if (c->cfg.model != PCM_MODEL_P2PLANE || c->tgt_dynamic || c->nlists_failed || (c->cfg.flags & PCM_FLAG_NO_NEIGHBOUR_LISTS)) return false;
+  if (c->cfg.flags & (PCM_FLAG_REFERENCE_KNN_ORDER | PCM_FLAG_COUNTED_SEARCH | PCM_FLAG_NO_LDS_STAGING | PCM_FLAG_FUSED_STEP)) return false;   // another kernel was asked for
+  return (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) != 0 || c->map_uses >= 2;
+}
+
 // lazy (re)build of everything the residual kernel needs
 int prepare(pcm_ctx* c) {
   if (c->src.n == 0 || c->tgt.n == 0) { c->err = "align before setInputSource/setInputTarget"; return PCM_ERR_NO_INPUT; }
@@ -255,6 +266,21 @@ int prepare(pcm_ctx* c) {
     c->stats.target_slots = c->map.cap;
     c->tgt_cov_valid = false;
     c->pleaf_valid = false;
+    c->nlists.valid = false;
+    c->nlists_failed = false;
+    c->map_uses = 0;
+  }
+  if (c->map_uses < 1000000) c->map_uses++;
+  if (uses_neighbour_lists(c) && (!c->nlists.valid || c->nlists.num_neighbors != c->cfg.num_neighbors)) {
+    // the candidate list of every voxel a query can fall into, built once per (static) target
+    int rc = build_neighbour_lists(c->stream, c->map, c->cfg.num_neighbors, &c->nlists, &c->err);
+    if (rc != PCM_OK) {
+      if (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) return rc;   // asked for explicitly
+      c->nlists_failed = true;                                   // e.g. no memory for them: the tile kernel serves this target
+      c->nlists.release();
+      c->err.clear();
+      (void)hipGetLastError();
+    }
   }
   if (c->cfg.model == PCM_MODEL_NDT_OMP) {
     // VoxelGridCovariance leaves (NormalDistributionsTransform::init, ndt_omp.h:300-306) + pass buffers
@@ -448,6 +474,7 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->tgt.inv_res = c->map.inv_res;
   d->tgt.res = c->map.res;
   d->tgt.gvox = c->map.gvox;
+  d->nl = (uses_neighbour_lists(c) && c->nlists.valid) ? view_of_lists(c->nlists) : TargetView{};
   d->src.pts = (c->cfg.sort_source && c->src_sorted) ? c->src_order : c->src.d_pts;
   if (is_gicp(c->cfg.model)) d->src.pts = c->srcmap.pts;   // brick-major copy of the scan: its covariances are in that order
   d->src_cov = c->src_cov;
@@ -620,6 +647,8 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   const bool write_sel = is_lm;  // trial passes re-use the planes of the selected set
   const bool counted_search = (g.flags & PCM_FLAG_COUNTED_SEARCH) != 0;   // k_linearize_counted (A/B)
   const bool ref_order = g.model == PCM_MODEL_P2PLANE && (g.flags & PCM_FLAG_REFERENCE_KNN_ORDER) != 0;   // neighbours in libstdc++'s nth_element order
+  bool lists = g.model == PCM_MODEL_P2PLANE && !ref_order;   // k_linearize_lists: every context of the batch holds its map's candidate lists
+  for (int i = 0; i < n && lists; i++) lists = uses_neighbour_lists(ctxs[i]) && ctxs[i]->nlists.valid;
   if (ref_order) {
     for (int i = 0; i < n; i++) {
       if (ctxs[i]->map.max_voxel_points > (uint32_t)kRefMaxVoxelPoints) {
@@ -664,6 +693,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
     else if (gicp) launch_gicp(st, w->d_descs, w->d_states, kpr, nl, g.model == PCM_MODEL_VGICP, false);
     else if (fuse) launch_linearize_fused(st, w->d_descs, w->d_states, kpr, lp, nl, w->d_flags + (size_t)r * n);
     else if (ref_order) launch_linearize_reforder(st, w->d_descs, w->d_states, kpr, nl, write_sel);
+    else if (lists && !counters_on && !timing_on) launch_linearize_lists(st, w->d_descs, w->d_states, kpr, nl, write_sel);
     else if (counted_search) launch_linearize_counted(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     else launch_linearize(st, w->d_descs, w->d_states, kpr, nl, write_sel, counters_on ? w->d_stats : nullptr, timing_on);
     if (timed) HIPCK(c0, hipEventRecord(w->ev_prof[prof_used + 1], st));
@@ -779,6 +809,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
     if (c->map.max_voxel_points > (uint32_t)kRefMaxVoxelPoints) { c->err = "PCM_FLAG_REFERENCE_KNN_ORDER supports at most " + std::to_string(kRefMaxVoxelPoints) + " points per voxel"; return PCM_ERR_UNSUPPORTED; }
     launch_linearize_reforder(c->stream, w->d_descs, w->d_states, kp1, 1, true);
   }
+  else if (linearize && uses_neighbour_lists(c) && c->nlists.valid) launch_linearize_lists(c->stream, w->d_descs, w->d_states, kp1, 1, true);
   else if (linearize && (c->cfg.flags & PCM_FLAG_COUNTED_SEARCH)) launch_linearize_counted(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);
@@ -1057,6 +1088,7 @@ void pcm_destroy(pcm_ctx* c) {
     c->map.release();
     c->srcmap.release();
     c->covfine.release();
+    c->nlists.release();
     if (c->corr) hipFree(c->corr);
     if (c->src_cov) hipFree(c->src_cov);
     if (c->tgt_cov) hipFree(c->tgt_cov);
@@ -1119,6 +1151,7 @@ int pcm_set_target(pcm_ctx* c, const void* points, size_t n, size_t stride_bytes
   c->user_cov[1].clear();   // target_covs_.clear()  fast_gicp_impl.hpp:89
   c->map.valid = false;
   c->map.index_n = 0;   // another log: the sorted index of the old one is of no use
+  c->tgt_dynamic = false;
   c->next_seq = (uint32_t)n;
   c->lio_planes_valid = false;
   return rc;
@@ -1764,6 +1797,7 @@ int pcm_target_insert(pcm_ctx* c, const void* points, size_t n, size_t stride_by
   c->next_seq += (uint32_t)n;
   c->tgt.tag = 0;
   c->map.valid = false;
+  c->tgt_dynamic = true;
   return PCM_OK;
 }
 
@@ -1788,7 +1822,7 @@ int pcm_map_incremental(pcm_ctx* c, const pcm_lio_state* s, float filter_size_ma
   c->tgt.n += added;
   c->next_seq += added;
   c->tgt.tag = 0;
-  if (added) c->map.valid = false;
+  if (added) { c->map.valid = false; c->tgt_dynamic = true; }
   if (num_added) *num_added = added;
   return PCM_OK;
 }

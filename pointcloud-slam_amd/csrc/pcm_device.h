@@ -202,6 +202,7 @@ struct LioPose {
 // per-pair descriptor read by the residual kernels
 struct PairDesc {
   TargetView tgt;
+  TargetView nl;         // P2PLANE with PCM_FLAG_NEIGHBOUR_LISTS: the candidate lists of the map (neighbour_lists.hip); pts == nullptr otherwise
   SourceView src;
   float4* planes;       // N: fitted plane of each scan point from the last linearize (w = d); x = NaN -> not selected
   LioPose lio;          // LIO measurement model only

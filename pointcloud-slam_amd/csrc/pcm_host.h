@@ -128,6 +128,20 @@ void launch_linearize(hipStream_t stream, const PairDesc* d_descs, const PairSta
                       unsigned long long* d_stats, bool timing);
 void launch_linearize_counted(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes,
                            unsigned long long* d_stats, bool timing = false);
+// per-voxel candidate lists of a static point-to-plane map (neighbour_lists.hip)
+struct NeighbourLists {
+  TargetMap index;            // brick hash over one stand-in point per voxel of the dilated occupied set: voxel -> list rank
+  uint32_t* start = nullptr;  // [num_lists + 1] first candidate of every list
+  float4* pts = nullptr;      // candidates, a list after the other, in the reference's visit order; w = index in the map's point array
+  size_t start_cap = 0, pts_cap = 0, num_candidates = 0;
+  uint32_t num_lists = 0;
+  int num_neighbors = 0;      // the neighbourhood the lists were built for
+  bool valid = false;
+  void release();
+};
+int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int num_neighbors, NeighbourLists* out, std::string* err);
+TargetView view_of_lists(const NeighbourLists& l);
+void launch_linearize_lists(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);
 void launch_linearize_reforder(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);
 void launch_linearize_fused(hipStream_t stream, const PairDesc* d_descs, PairState* d_states, const KernelParams& kp, const LsqParams& lp, int npairs, unsigned char* d_flags_row);
 void launch_lio_obs(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp);
@@ -168,6 +182,10 @@ struct pcm_ctx {
   pcm::Cloud src, tgt;
   pcm::TargetMap map;
   pcm::TargetMap srcmap;          // NDT D2D: the source's own voxel distributions
+  bool tgt_dynamic = false;       // the target grew since pcm_set_target (pcm_target_insert / pcm_map_incremental)
+  bool nlists_failed = false;     // the lists of this map could not be built (memory): not tried again
+  int map_uses = 0;               // prepare() calls since the map was (re)built
+  pcm::NeighbourLists nlists;     // P2PLANE, PCM_FLAG_NEIGHBOUR_LISTS: candidate lists of `map` (static targets)
   pcm::TargetMap covfine;         // GICP: the cloud whose covariances are being computed, on a grid 8x finer (kNN index of dense neighbourhoods only)
   int32_t* corr = nullptr;        // NDT: matched voxel per (element, offset) of the last linearize
   size_t corr_cap = 0;

@@ -8,7 +8,7 @@ O=gpurun_out/r03final
 mkdir -p $O
 python tools/gen_cache.py --pairs 64 > $O/gen.log 2>&1
 B="python3 bench.py --cpu-seconds 0 --pairs-cache /tmp/pcm_pairs.npz"
-K="k_linearize<false, false"
+K="k_linearize_lists<false"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/pmc_sq -o pmc -- $B --steps 2 --warmup 2 > $O/pmc_sq.log 2>&1
 python tools/pmc_valu.py $O/pmc_sq "$K" 100000_1000000_64_GN $O/pmc_valu.json > /dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o pmc -- $B --steps 2 --warmup 2 > $O/pmc_fetch.log 2>&1
