@@ -201,7 +201,12 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on STDOUT when the first communicator is created: stdout is kept for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if args.backend == "nccl":
             dist.init_process_group("nccl")   # backend "nccl" is RCCL on ROCm; communicators are created by the warm-up collectives below
         else:
@@ -255,6 +260,9 @@ def main():
     if use_dist:   # create the communicator before the timed region
         dist.all_reduce(torch.zeros(1, device=dev))
         torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     def sub_step(j, before_results=None):
         """One pass of the hot path on slot j: over the whole batch (rotate) or over sub-batch j (split)."""
@@ -269,11 +277,16 @@ def main():
         for k, r in enumerate(mine):
             r.set_input_source(d_inputs[lo + k][0])
         if before_results is not None:
+            t_w = time.perf_counter()
             before_results()     # the gather of this slot's previous result block has been issued and has finished
+            comm_times["wait_prev_s"] += time.perf_counter() - t_w
         return pcm.align_batch(mine, guesses[lo:hi], device_out=out_ptr)
+
+    comm_times = {"gather_s": 0.0, "wait_prev_s": 0.0, "gathers": 0}   # host time inside the collective thread / a slot waiting for it
 
     def gather_slot(j):
         """RCCL all-gather of slot j's solved poses over xGMI (one small collective), complete on return."""
+        t_g = time.perf_counter()
         with torch.cuda.stream(comm_stream):
             if rotate:
                 got = sharding.gather_records(d_results[j * n_local * rec:(j + 1) * n_local * rec], world)
@@ -283,6 +296,8 @@ def main():
                 got = sharding.gather_records(d_results[lo * rec:hi * rec], world)
                 d_gather.view(world, n_local * rec)[:, lo * rec:hi * rec].copy_(got)
         comm_stream.synchronize()
+        comm_times["gather_s"] += time.perf_counter() - t_g
+        comm_times["gathers"] += 1
 
     def run_steps(k, stagger_s=0.0):
         """k passes over the batch; returns the results of the last one (sharding.run_rotating_steps / run_pipelined_steps:
@@ -436,7 +451,10 @@ def main():
                                    % (args.scan_points, args.map_points, args.optimizer, n_local),
                        "pairs_per_gpu": n_local, "batches_in_flight": S, "schedule": args.schedule, "voxel_m": cfg["voxel_resolution"], "neighbors": cfg["num_neighbors"],
                        "flags": args.flags, "search_kernel": search_kernel,
-                       "target_reuse": True, "collectives_executed": bool(use_dist), "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
+                       "target_reuse": True, "collectives_executed": bool(use_dist),
+                       "gather_ms_per_pass": (1e3 * comm_times["gather_s"] / max(1, comm_times["gathers"])) if use_dist else None,
+                       "slot_wait_for_gather_ms_per_pass": (1e3 * comm_times["wait_prev_s"] / max(1, comm_times["gathers"])) if use_dist else None,
+                       "parallelism": "independent pairs sharded over %d GPU(s), %s all_gather of poses (one communicator, collectives issued in (step, slot) order by one thread)" % (world, "RCCL" if args.backend == "nccl" else "gloo (rehearsal, ranks share a GPU)"),
                        "mean_linearize_passes": float(np.mean(iters)), "converged": int(sum(r.converged for r in res)),
                        "cold_registrations_per_s": n_local * world / t_cold, "gen_s": t_gen, "gathered_ok": gathered_ok},
             "roofline": roof,

@@ -187,7 +187,7 @@ def gather_records(local_records, world: int, group=None):
     """
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not dist.is_initialized():   # a process group of one rank still runs the collective (bench.py --collectives-at-one)
         return local_records.view(1, -1)
     if local_records.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsal of the N>1 control flow on a box with fewer GPUs than ranks: gloo moves host bytes
