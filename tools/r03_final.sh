@@ -19,8 +19,5 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -20 $O
 python -c "import json; d=json.load(open('$O/bench_default.json')); r=d['roofline']; print('bench', round(d['value']), d['ms_per_step'], 'valu frac', r['frac'], 'alone', r.get('kernel_alone_frac'), 'hbm frac', r.get('hbm_frac_physical'), d['config']['parity_ok'], d['cpu_baseline']['value'], d['cpu_baseline']['one_thread']['value'])"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -o kt -- $B --steps 20 --warmup 3 > $O/kt_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_single -o kt -- $B --steps 20 --warmup 3 --pipeline 1 > $O/kt_single.log 2>&1
-# the N>1 code path (process group, per-pass all-gather of the packed results on the communication stream) at world size 1: RCCL executes
-timeout -k 10 300 python bench.py --collectives-at-one 1 --cpu-seconds 0 --pairs-cache /tmp/pcm_pairs.npz --steps 20 --warmup 3 > $O/bench_rccl_world1.json 2> $O/bench_rccl_world1.err || tail -5 $O/bench_rccl_world1.err
-python -c "import json; d=json.load(open('$O/bench_rccl_world1.json')); print('rccl world 1:', round(d['value']), d['config']['collectives_executed'], d['config']['gathered_ok'])"
 find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 grep -o '"value": [0-9.]*' $O/kt_default.log $O/kt_single.log
