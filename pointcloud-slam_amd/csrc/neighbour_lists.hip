@@ -144,6 +144,15 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
   const uint32_t nvox = map.num_voxels;
   const size_t nk = (size_t)nvox * nn;
   if (nk >= (1ull << 31) || (size_t)map.num_points * nn >= (1ull << 32)) { *err = "neighbour lists: map too large"; return PCM_ERR_UNSUPPORTED; }
+  {   // room for them?  27 x 16 B per map point for the lists, ~56 B per (voxel, offset) key while they are built; a quarter of the
+      // free memory stays untouched (the caller's next targets, the scratch of the passes)
+    size_t free_b = 0, total_b = 0;
+    const size_t need = (size_t)map.num_points * nn * sizeof(float4) + nk * 56 + ((size_t)64 << 20);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b - free_b / 4) {
+      *err = "neighbour lists: " + std::to_string(need >> 20) + " MiB needed, " + std::to_string(free_b >> 20) + " MiB of device memory free";
+      return PCM_ERR_HIP;
+    }
+  }
   uint64_t *keys = nullptr, *keys_s = nullptr;
   uint32_t *flag = nullptr, *pos = nullptr, *d_cnt = nullptr, *len = nullptr;
   float4* centres = nullptr;
