@@ -3,7 +3,9 @@
 //   k_linearize      one launch per GN / LM round: 5-NN of every scan point in the brick voxel hash of the
 //                    submap, plane fit, point-to-plane residual / Jacobian and the 29 normal-equation sums
 //                    of the tile (one partial row per 256-point workgroup); LIO variant: the 12-column IEKF
-//                    measurement row and its 92 sums
+//                    measurement row and its 92 sums.  The tile kernel: a target's first registration, growing
+//                    (sliding) targets and the LIO model; a static target that is registered against again
+//                    runs k_linearize_lists (neighbour_lists.hip) on candidate lists built with its map
 //   k_finish_round   fixed-order sum of the partial rows + the GN / LM state machine (lsq_step.h), one
 //                    status byte per pair into mapped host memory
 //   k_trial          LM trial cost on the planes of the last linearize

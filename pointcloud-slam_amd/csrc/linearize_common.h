@@ -1,5 +1,6 @@
-// linearize_common.h -- device helpers shared by the point-to-plane search kernels (kernels.hip: the per-cell LDS search and
-// the LIO variant; linearize_flat.hip: the flat candidate-list search): neighbour-cell tables in the reference's order
+// linearize_common.h -- device helpers shared by the point-to-plane search kernels (kernels.hip: the per-tile LDS search and
+// the LIO variant; neighbour_lists.hip: the walk of per-voxel candidate lists; linearize_counted.hip, linearize_reforder.hip):
+// neighbour-cell tables in the reference's order
 // (jueying_lio/include/ivox3d/ivox3d.h:211-235), the float pose transform of laser_mapping.cc:602-612, the running 5-best list
 // of IVoxNode::KNNPointByCondition / IVox::GetClosestPoint (ivox3d_node.hpp:140-205, ivox3d.h:132-204) and the per-lane search
 // against the global brick hash.
