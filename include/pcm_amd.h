@@ -129,7 +129,9 @@ typedef struct pcm_config {
                                        * on the device (neighbour_lists.hip) -- instead of re-deriving the candidates per pass through LDS.  Same candidates
                                        * in the same order: bit-identical results, 1.8x the kernel speed.  DEFAULT: the lists are built when a target is
                                        * registered against the second time; this flag builds them with the map (first registration already).  Never for a
-                                       * target that has grown (pcm_target_insert / pcm_map_incremental), the LIO model, or next to another kernel flag. */
+                                       * target that has grown (pcm_target_insert / pcm_map_incremental), the LIO model, or next to another kernel flag.
+                                       * pclomp NDT (PCM_MODEL_NDT_OMP): the same policy for the grid's neighbour-LEAF lists (the leaves a point's search
+                                       * visits, in visiting order; 16 B per (voxel, neighbour leaf)). */
 #define PCM_FLAG_NO_NEIGHBOUR_LISTS 64 /* never build them: the tile kernel (kernels.hip) serves every pass */
 #define PCM_FLAG_REFERENCE_KNN_ORDER 32
 /* P2PLANE align / linearize: hand esti_plane its neighbours in the row order the reference's IVox::GetClosestPoint leaves -- the

@@ -36,11 +36,11 @@ constexpr int kKeyBias = 1 << 20;
 __device__ inline uint64_t nl_pack(int x, int y, int z) { return ((uint64_t)(uint32_t)(x + kKeyBias) << 42) | ((uint64_t)(uint32_t)(y + kKeyBias) << 21) | (uint64_t)(uint32_t)(z + kKeyBias); }
 
 // one key per (occupied voxel, neighbour offset): the voxels a query can sit in and see this voxel.  grid = ceil(nvox / 256)
-__global__ void k_nl_keys(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, uint32_t nvox, float inv_res, int nn, uint64_t* __restrict__ keys) {
+__global__ void k_nl_keys(const float4* __restrict__ pts, const uint32_t* __restrict__ vox_start, uint32_t nvox, float res, float inv_res, int mode, int nn, uint64_t* __restrict__ keys) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
   const float4 p = pts[vox_start[v]];
-  const int cx = (int)roundf(p.x * inv_res), cy = (int)roundf(p.y * inv_res), cz = (int)roundf(p.z * inv_res);   // Pos2Grid  ivox3d.h:283-286
+  const int cx = voxel_coord(p.x, res, inv_res, mode), cy = voxel_coord(p.y, res, inv_res, mode), cz = voxel_coord(p.z, res, inv_res, mode);   // the map's own convention (Pos2Grid  ivox3d.h:283-286; pclomp: floor(p * inverse_leaf_size))
   const int lim = kKeyBias - 64;
   for (int g = 0; g < nn; g++) {
     const int x = cx - c_nearby[g][0], y = cy - c_nearby[g][1], z = cz - c_nearby[g][2];   // u + nearby[g] = this voxel
@@ -56,7 +56,7 @@ __global__ void k_nl_flags(const uint64_t* __restrict__ keys, uint32_t n, uint32
 }
 
 // the stand-in point of every distinct key: the centre of its voxel (Pos2Grid of it is the voxel again)
-__global__ void k_nl_centres(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n, float res, float4* __restrict__ out,
+__global__ void k_nl_centres(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint32_t n, float res, float shift, float4* __restrict__ out,
                              uint32_t* __restrict__ count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -64,7 +64,7 @@ __global__ void k_nl_centres(const uint64_t* __restrict__ keys, const uint32_t* 
   if (!flag[i]) return;
   const uint64_t k = keys[i];
   const int x = (int)((k >> 42) & 0x1fffffu) - kKeyBias, y = (int)((k >> 21) & 0x1fffffu) - kKeyBias, z = (int)(k & 0x1fffffu) - kKeyBias;
-  out[pos[i]] = make_float4((float)x * res, (float)y * res, (float)z * res, 0.f);
+  out[pos[i]] = make_float4(((float)x + shift) * res, ((float)y + shift) * res, ((float)z + shift) * res, 0.f);   // shift: 0 (round) or 0.5 (floor): the voxel's centre
 }
 
 // the run of voxel (vx, vy, vz) in the map's point array (brick probe re-used while consecutive cells stay in one brick)
@@ -111,6 +111,53 @@ __global__ void k_nl_lists(const float4* __restrict__ centres, uint32_t nd, Targ
   if (!FILL) len[r] = n;
 }
 
+// pclomp NDT: the neighbour LEAVES of every list voxel in the order getNeighborhoodAtPoint{,7,1} / the radius search visit them
+// (voxel_grid_covariance_omp_impl.hpp:373-442; pcl::getAllNeighborCellIndices order for the 27 cells), filtered as far as the filter
+// does not depend on the query: DIRECT1/7/27 keep a leaf with >= 6 points; KDTREE (nn = 0) keeps a leaf of the centroid cloud and
+// stores its float centroid for the radius test the pass applies per point.  Entry = (centroid xyz or 0, leaf index).
+__device__ inline void nl_ndt_offset(int nO, int k, int& ox, int& oy, int& oz) {
+  if (nO == 27) { ox = k / 9 - 1; oy = (k / 3) % 3 - 1; oz = k % 3 - 1; return; }
+  ox = oy = oz = 0;
+  if (k == 1) ox = 1; else if (k == 2) ox = -1; else if (k == 3) oy = 1; else if (k == 4) oy = -1; else if (k == 5) oz = 1; else if (k == 6) oz = -1;
+}
+__device__ inline int nl_voxel_rank(const TargetView& tg, BrickCursor& c, int vx, int vy, int vz) {
+  const int bx = vx >> kBrickShift, by = vy >> kBrickShift, bz = vz >> kBrickShift;
+  if (bx != c.bx || by != c.by || bz != c.bz) {
+    uint32_t np = 0;
+    c.slot = brick_find<false>(tg, bx, by, bz, c.base, np);
+    c.bx = bx; c.by = by; c.bz = bz;
+  }
+  if (c.slot == ~0u) return -1;
+  const uint32_t li = local_index(vx, vy, vz), w = li >> 5, bit = li & 31;
+  const uint32_t m = gload_u(&tg.bmask[(size_t)c.slot * 16 + w]);
+  if (!((m >> bit) & 1u)) return -1;
+  return (int)(c.base + gload_u16(&tg.bpref[(size_t)c.slot * 16 + w]) + (uint32_t)__popc(m & ((1u << bit) - 1u)));
+}
+template <bool FILL>
+__global__ void k_nl_leaf_lists(const float4* __restrict__ centres, uint32_t nd, TargetView tg, int mode, const PclLeaf* __restrict__ leaves, int nn, uint32_t* __restrict__ len,
+                                const uint32_t* __restrict__ start, float4* __restrict__ out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nd) return;
+  const float4 c = centres[r];
+  const int cx = voxel_coord(c.x, tg.res, tg.inv_res, mode), cy = voxel_coord(c.y, tg.res, tg.inv_res, mode), cz = voxel_coord(c.z, tg.res, tg.inv_res, mode);
+  const int nk = nn == 0 ? 27 : nn;
+  BrickCursor cur;
+  uint32_t n = 0;
+  const uint32_t o = FILL ? start[r] : 0u;
+  for (int k = 0; k < nk; k++) {
+    int ox, oy, oz;
+    nl_ndt_offset(nk, k, ox, oy, oz);
+    const int v = nl_voxel_rank(tg, cur, cx + ox, cy + oy, cz + oz);
+    if (v < 0) continue;
+    const PclLeaf* L = leaves + v;
+    const bool keep = nn == 0 ? L->in_centroids != 0 : L->n >= 6;
+    if (!keep) continue;
+    if (FILL) out[o + n] = nn == 0 ? make_float4(L->centroid[0], L->centroid[1], L->centroid[2], __int_as_float(v)) : make_float4(0.f, 0.f, 0.f, __int_as_float(v));
+    n++;
+  }
+  if (!FILL) len[r] = n;
+}
+
 TargetView view_of_map(const TargetMap& m) {
   TargetView v{};
   v.pts = m.pts; v.vox_start = m.vox_start; v.bricks = m.bricks; v.bmask = m.bmask; v.bpref = m.bpref; v.gvox = m.gvox;
@@ -124,7 +171,7 @@ void NeighbourLists::release() {
   index.release();
   if (start) hipFree(start);
   if (pts) hipFree(pts);
-  start = nullptr; pts = nullptr; start_cap = 0; pts_cap = 0; num_lists = 0; num_candidates = 0; num_neighbors = 0; valid = false;
+  start = nullptr; pts = nullptr; start_cap = 0; pts_cap = 0; num_lists = 0; num_candidates = 0; num_neighbors = 0; valid = false; for_ndt = false;
 }
 
 TargetView view_of_lists(const NeighbourLists& l) {
@@ -135,19 +182,22 @@ TargetView view_of_lists(const NeighbourLists& l) {
   return v;
 }
 
-// Build the candidate lists of `map` for the neighbourhood `nn` (7 / 19 / 27 cells).  Host syncs: the number of dilated voxels, the
-// index build's own, the total list length.
-int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, NeighbourLists* out, std::string* err) {
+// Build the candidate lists of `map` for the neighbourhood `nn` (7 / 19 / 27 cells); with `ndt_leaves` (pclomp NDT: nn = 0 for the
+// KDTREE search, 1 / 7 / 27) the lists hold neighbour LEAVES instead of points.  Host syncs: the number of dilated voxels, the index
+// build's own, the total list length.
+int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, NeighbourLists* out, std::string* err, const PclLeaf* ndt_leaves) {
   out->valid = false;
-  if (!map.valid || map.coord_mode != COORD_ROUND) { *err = "neighbour lists need a point-to-plane map"; return PCM_ERR_UNSUPPORTED; }
-  if (nn != 1 && nn != 7 && nn != 19 && nn != 27) { *err = "neighbour lists: num_neighbors must be 1, 7, 19 or 27"; return PCM_ERR_INVALID_ARGUMENT; }
+  const int mode = map.coord_mode;
+  if (!map.valid || (mode != COORD_ROUND && mode != COORD_FLOOR_MUL)) { *err = "neighbour lists need a point-to-plane or pclomp NDT map"; return PCM_ERR_UNSUPPORTED; }
+  if (ndt_leaves ? (nn != 0 && nn != 1 && nn != 7 && nn != 27) : (nn != 1 && nn != 7 && nn != 19 && nn != 27)) { *err = "neighbour lists: unsupported neighbourhood"; return PCM_ERR_INVALID_ARGUMENT; }
+  const int nset = nn == 0 ? 27 : nn;   // cells of the neighbourhood (the SET is the same in the iVox and the pcl order: c_nearby's prefixes)
   const uint32_t nvox = map.num_voxels;
-  const size_t nk = (size_t)nvox * nn;
-  if (nk >= (1ull << 31) || (size_t)map.num_points * nn >= (1ull << 32)) { *err = "neighbour lists: map too large"; return PCM_ERR_UNSUPPORTED; }
+  const size_t nk = (size_t)nvox * nset;
+  if (nk >= (1ull << 31) || (size_t)map.num_points * nset >= (1ull << 32)) { *err = "neighbour lists: map too large"; return PCM_ERR_UNSUPPORTED; }
   {   // room for them?  27 x 16 B per map point for the lists, ~56 B per (voxel, offset) key while they are built; a quarter of the
       // free memory stays untouched (the caller's next targets, the scratch of the passes)
     size_t free_b = 0, total_b = 0;
-    const size_t need = (size_t)map.num_points * nn * sizeof(float4) + nk * 56 + ((size_t)64 << 20);
+    const size_t need = (ndt_leaves ? (size_t)nvox : (size_t)map.num_points) * nset * sizeof(float4) + nk * 56 + ((size_t)64 << 20);
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b - free_b / 4) {
       *err = "neighbour lists: " + std::to_string(need >> 20) + " MiB needed, " + std::to_string(free_b >> 20) + " MiB of device memory free";
       return PCM_ERR_HIP;
@@ -172,7 +222,7 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
     CK(hipMallocAsync(reinterpret_cast<void**>(&flag), sizeof(uint32_t) * nk, stream));
     CK(hipMallocAsync(reinterpret_cast<void**>(&pos), sizeof(uint32_t) * nk, stream));
     CK(hipMallocAsync(reinterpret_cast<void**>(&d_cnt), sizeof(uint32_t) * 2, stream));
-    k_nl_keys<<<(nvox + 255) / 256, 256, 0, stream>>>(map.pts, map.vox_start, nvox, map.inv_res, nn, keys);
+    k_nl_keys<<<(nvox + 255) / 256, 256, 0, stream>>>(map.pts, map.vox_start, nvox, map.res, map.inv_res, mode, nset, keys);
     CK(hipGetLastError());
     CK(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, keys_s, nk, 0, 64, stream));
     CK(hipMallocAsync(&tmp, tmp_bytes, stream));
@@ -183,14 +233,14 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
     CK(hipMallocAsync(&tmp2, tmp2_bytes, stream));
     CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, flag, pos, 0u, nk, rocprim::plus<uint32_t>(), stream));
     CK(hipMallocAsync(reinterpret_cast<void**>(&centres), sizeof(float4) * nk, stream));   // at most one per key
-    k_nl_centres<<<nb, 256, 0, stream>>>(keys_s, flag, pos, (uint32_t)nk, map.res, centres, d_cnt);
+    k_nl_centres<<<nb, 256, 0, stream>>>(keys_s, flag, pos, (uint32_t)nk, map.res, mode == COORD_ROUND ? 0.f : 0.5f, centres, d_cnt);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(&h_cnt[0], d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CK(hipStreamSynchronize(stream));
     uint32_t nd = h_cnt[0];
     if (nd == 0) { *err = "neighbour lists: empty map"; rc = PCM_ERR_NO_INPUT; goto done; }
     // the list index: a brick hash over the stand-in points (one per dilated voxel)
-    rc = build_target_map(stream, centres, &nd, map.res, COORD_ROUND, false, 0u, &out->index, err);
+    rc = build_target_map(stream, centres, &nd, map.res, mode, false, 0u, &out->index, err);
     if (rc != PCM_OK) goto done;
     if (out->index.num_voxels != nd || out->index.num_points != nd) { *err = "neighbour lists: index does not hold one voxel per list"; rc = PCM_ERR_INTERNAL; goto done; }
     // list lengths -> starts -> candidates
@@ -202,7 +252,8 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
     }
     CK(hipMallocAsync(reinterpret_cast<void**>(&len), sizeof(uint32_t) * ((size_t)nd + 1), stream));
     CK(hipMemsetAsync(len, 0, sizeof(uint32_t) * ((size_t)nd + 1), stream));
-    k_nl_lists<false><<<(nd + 127) / 128, 128, 0, stream>>>(out->index.pts, nd, view_of_map(map), nn, len, nullptr, nullptr);
+    if (ndt_leaves) k_nl_leaf_lists<false><<<(nd + 127) / 128, 128, 0, stream>>>(out->index.pts, nd, view_of_map(map), mode, ndt_leaves, nn, len, nullptr, nullptr);
+    else k_nl_lists<false><<<(nd + 127) / 128, 128, 0, stream>>>(out->index.pts, nd, view_of_map(map), nn, len, nullptr, nullptr);
     CK(hipGetLastError());
     CK(rocprim::exclusive_scan(nullptr, tmp3_bytes, len, out->start, 0u, (size_t)nd + 1, rocprim::plus<uint32_t>(), stream));
     CK(hipMallocAsync(&tmp3, tmp3_bytes, stream));
@@ -217,12 +268,14 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
       out->pts_cap = total + 4;
     }
     CK(hipMemsetAsync(out->pts + total, 0, sizeof(float4) * 4, stream));
-    k_nl_lists<true><<<(nd + 127) / 128, 128, 0, stream>>>(out->index.pts, nd, view_of_map(map), nn, nullptr, out->start, out->pts);
+    if (ndt_leaves) k_nl_leaf_lists<true><<<(nd + 127) / 128, 128, 0, stream>>>(out->index.pts, nd, view_of_map(map), mode, ndt_leaves, nn, nullptr, out->start, out->pts);
+    else k_nl_lists<true><<<(nd + 127) / 128, 128, 0, stream>>>(out->index.pts, nd, view_of_map(map), nn, nullptr, out->start, out->pts);
     CK(hipGetLastError());
     CK(hipStreamSynchronize(stream));
     out->num_lists = nd;
     out->num_candidates = total;
     out->num_neighbors = nn;
+    out->for_ndt = ndt_leaves != nullptr;
     out->valid = true;
   }
 done:

@@ -166,8 +166,53 @@ __device__ inline int neighbour_leaf(const TargetView& tg, const PclLeaf* leaves
 // share it unless the cell lies on a brick face), then every cell's mask word, prefix and leaf header are loaded by straight-line
 // code -- independent loads, in flight together.  v[0 .. count) = the leaves that take part, in the reference's cell order.
 constexpr int kNdtMaxCells = 27;
-__device__ inline int neighbour_leaves(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, int nn, int cx, int cy, int cz, const float (&xt)[3],
-                                       int* __restrict__ v /* LDS, stride 256 */) {
+__device__ inline uint32_t brick_find_ndt(const TargetView& tg, int bx, int by, int bz, uint32_t& vox_base) {
+  const uint64_t key = pack_brick(bx, by, bz);
+  uint32_t h = hash_coord(bx, by, bz) & tg.mask;
+  for (;;) {
+    const uint4 s = gload4u(&tg.bricks[h]);
+    const uint64_t sk = slot_key3(s);
+    if (sk == key) { vox_base = s.z; return h; }
+    if (sk == kEmptyKey) { vox_base = 0; return ~0u; }
+    h = (h + 1) & tg.mask;
+  }
+}
+__device__ inline int neighbour_leaves(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const TargetView& nl, int nn, int cx, int cy, int cz,
+                                       const float (&xt)[3], int* __restrict__ v /* LDS, stride 256 */) {
+  if (nl.pts) {
+    // the grid's neighbour-leaf lists (built with a target that is registered against again: neighbour_lists.hip): one probe of the
+    // list index, then one contiguous run of (centroid, leaf) entries in the order the cells would have been visited -- the 27-cell
+    // searches no longer cost 27 mask words, prefixes and leaf headers per point
+    int cnt = 0;
+    uint32_t base = 0, np = 0;
+    const uint32_t slot = brick_find_ndt(nl, cx >> kBrickShift, cy >> kBrickShift, cz >> kBrickShift, base);
+    (void)np;
+    if (slot == ~0u) return 0;
+    const uint32_t li = local_index(cx, cy, cz), w = li >> 5, bit = li & 31;
+    const uint32_t m = gload_u(&nl.bmask[(size_t)slot * 16 + w]);
+    if (!((m >> bit) & 1u)) return 0;
+    const uint32_t r = base + gload_u16(&nl.bpref[(size_t)slot * 16 + w]) + (uint32_t)__popc(m & ((1u << bit) - 1u));
+    const uint32_t s = gload_u(&nl.vox_start[r]), e = gload_u(&nl.vox_start[r + 1]);
+    const float r2 = (float)((double)tg.res * (double)tg.res);
+    for (uint32_t k = s; k < e; k += 4) {   // padded array: a load past the run is never used
+      const float4 e0 = gload4(nl.pts + k), e1 = gload4(nl.pts + k + 1), e2 = gload4(nl.pts + k + 2), e3 = gload4(nl.pts + k + 3);
+      const float4 en[4] = {e0, e1, e2, e3};
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (k + u >= e) break;
+        bool ok = true;
+        if (nn == 0) {   // KDTREE = radiusSearch(point, resolution) over the centroid cloud: float squared distance strictly below radius^2
+          float d2 = 0.0f;
+          const float df0 = xt[0] - en[u].x; d2 += df0 * df0;
+          const float df1 = xt[1] - en[u].y; d2 += df1 * df1;
+          const float df2 = xt[2] - en[u].z; d2 += df2 * df2;
+          ok = d2 < r2;
+        }
+        if (ok) { v[cnt * 256] = __float_as_int(en[u].w); cnt++; }
+      }
+    }
+    return cnt;
+  }
   const int nk = nn == 0 ? 27 : nn;
   const int cbx = cx >> kBrickShift, cby = cy >> kBrickShift, cbz = cz >> kBrickShift;
   int ch = -1;
@@ -266,8 +311,8 @@ __device__ inline void block_reduce_store(double (&acc)[NS], double* dst) {
 // grid = blocks, block = 256, `per` points per workgroup
 // ---------------------------------------------------------------------------
 template <bool HESS>
-__device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per,
-                                               const NdtOmpParams& P,
+__device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const TargetView& nl, const float4* __restrict__ src, uint32_t n,
+                                               uint32_t per, const NdtOmpParams& P,
                                                double* __restrict__ partials, int* __restrict__ s_leaf /* LDS [kNdtMaxCells][256]: the neighbour leaves of every lane's current point */) {
   const uint32_t begin = blockIdx.x * per;
   uint32_t end = begin + per;
@@ -305,7 +350,7 @@ __device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLe
       for (int j = 0; j < 6; j++) pg[a][j] = (a == j) ? 1.0f : 0.0f;
     }
     pg[1][3] = xj[0]; pg[2][3] = xj[1]; pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4]; pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
-    const int cnt = neighbour_leaves(tg, leaves, leaves_f, P.num_neighbors, cx, cy, cz, xt, s_leaf + threadIdx.x);
+    const int cnt = neighbour_leaves(tg, leaves, leaves_f, nl, P.num_neighbors, cx, cy, cz, xt, s_leaf + threadIdx.x);
     for (int k = 0; k < cnt; k++) {
       // the leaf's 64-byte line (mean in double, (float)icov): four 16-byte loads.  (Fetching the next leaf's line while this one is
       // worked on costs 16 more live registers in a body that is already capped at 255: 55 spilled dwords instead of 15, 2 148 ->
@@ -374,8 +419,8 @@ __device__ inline void pclndt_derivatives_body(const TargetView& tg, const PclLe
 // ---------------------------------------------------------------------------
 // k_pclndt_hessian: computeHessian / updateHessian in double  :498-590
 // ---------------------------------------------------------------------------
-__device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per,
-                                           const NdtOmpParams& P,
+__device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const TargetView& nl, const float4* __restrict__ src, uint32_t n,
+                                           uint32_t per, const NdtOmpParams& P,
                                            double* __restrict__ partials, int* __restrict__ s_leaf) {
   const uint32_t begin = blockIdx.x * per;
   uint32_t end = begin + per;
@@ -406,7 +451,7 @@ __device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* 
                  vc[3] = {0.0, PCM_DOT3(P.h_ang_d[4]), PCM_DOT3(P.h_ang_d[5])}, vd[3] = {PCM_DOT3(P.h_ang_d[6]), PCM_DOT3(P.h_ang_d[7]), PCM_DOT3(P.h_ang_d[8])},
                  ve[3] = {PCM_DOT3(P.h_ang_d[9]), PCM_DOT3(P.h_ang_d[10]), PCM_DOT3(P.h_ang_d[11])}, vf[3] = {PCM_DOT3(P.h_ang_d[12]), PCM_DOT3(P.h_ang_d[13]), PCM_DOT3(P.h_ang_d[14])};
 #undef PCM_DOT3
-    const int cnt = neighbour_leaves(tg, leaves, leaves_f, P.num_neighbors, cx, cy, cz, xt, s_leaf + threadIdx.x);
+    const int cnt = neighbour_leaves(tg, leaves, leaves_f, nl, P.num_neighbors, cx, cy, cz, xt, s_leaf + threadIdx.x);
     for (int k = 0; k < cnt; k++) {
       const PclLeaf* L = leaves + s_leaf[k * 256 + threadIdx.x];
       double xt3[3], ic[9], cxv[3];
@@ -446,15 +491,15 @@ __device__ inline void pclndt_hessian_body(const TargetView& tg, const PclLeaf* 
 
 // one object, the parameters in the kernel arguments (pcm_ndt_derivatives, the host-driven solver)
 template <bool HESS>
-__global__ void __launch_bounds__(256, 2) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+__global__ void __launch_bounds__(256, 2) k_pclndt_derivatives(TargetView tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, TargetView nl, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
                                                             double* __restrict__ partials) {
   __shared__ int s_leaf[kNdtMaxCells * 256];
-  pclndt_derivatives_body<HESS>(tg, leaves, leaves_f, src, n, per, P, partials, s_leaf);
+  pclndt_derivatives_body<HESS>(tg, leaves, leaves_f, nl, src, n, per, P, partials, s_leaf);
 }
-__global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
+__global__ void __launch_bounds__(256) k_pclndt_hessian(TargetView tg, const PclLeaf* __restrict__ leaves, const PclLeafF* __restrict__ leaves_f, TargetView nl, const float4* __restrict__ src, uint32_t n, uint32_t per, NdtOmpParams P,
                                                         double* __restrict__ partials) {
   __shared__ int s_leaf[kNdtMaxCells * 256];
-  pclndt_hessian_body(tg, leaves, leaves_f, src, n, per, P, partials, s_leaf);
+  pclndt_hessian_body(tg, leaves, leaves_f, nl, src, n, per, P, partials, s_leaf);
 }
 
 // ---------------------------------------------------------------------------
@@ -472,9 +517,9 @@ __global__ void __launch_bounds__(256, 2) k_pclndt_batch_pass(const NdtObject* _
   if (req < 0 || blockIdx.x >= (uint32_t)ob.nblocks) return;
   const NdtOmpParams& P = ms[blockIdx.y].P;
   __shared__ int s_leaf[kNdtMaxCells * 256];
-  if (req == 0) pclndt_derivatives_body<true>(ob.tg, ob.leaves, ob.leaves_f, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
-  else if (req == 1) pclndt_derivatives_body<false>(ob.tg, ob.leaves, ob.leaves_f, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
-  else pclndt_hessian_body(ob.tg, ob.leaves, ob.leaves_f, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
+  if (req == 0) pclndt_derivatives_body<true>(ob.tg, ob.leaves, ob.leaves_f, ob.nl, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
+  else if (req == 1) pclndt_derivatives_body<false>(ob.tg, ob.leaves, ob.leaves_f, ob.nl, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
+  else pclndt_hessian_body(ob.tg, ob.leaves, ob.leaves_f, ob.nl, ob.src, ob.n, ob.per, P, ob.partials, s_leaf);
 }
 
 // JacobiSVD<Matrix6d>(H, ComputeFullU | ComputeFullV).solve(b) by the whole workgroup: the arithmetic of pcm::svd_solve6 /
@@ -704,9 +749,9 @@ void launch_pclndt_batch_round(hipStream_t stream, const NdtObject* d_objs, ndto
   k_pclndt_batch_step<<<nobj, 64, 0, stream>>>(d_objs, d_ms, d_flags_row);
 }
 
-NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, double* d_partials) {
+NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const TargetView& nl, const float4* src, uint32_t n, double* d_partials) {
   NdtObject ob{};
-  ob.tg = view_of2(map); ob.leaves = leaves; ob.leaves_f = leaves_f; ob.src = src; ob.n = n;
+  ob.tg = view_of2(map); ob.leaves = leaves; ob.leaves_f = leaves_f; ob.nl = nl; ob.src = src; ob.n = n;
   ob.nblocks = pclndt_workgroups(n, &ob.per);
   ob.partials = d_partials;
   return ob;
@@ -723,13 +768,13 @@ int pclndt_workgroups(uint32_t n, uint32_t* per_out) {
 }
 
 // one derivatives (or Hessian-only) pass; the 48-double result row lands in d_out
-void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const TargetView& nl, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
                         double gauss_d3) {
   uint32_t per = 0;
   const int nb = pclndt_workgroups(n, &per);
-  if (pass == 0) k_pclndt_derivatives<true><<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, src, n, per, P, d_partials);
-  else if (pass == 1) k_pclndt_derivatives<false><<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, src, n, per, P, d_partials);
-  else if (pass == 2) k_pclndt_hessian<<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, src, n, per, P, d_partials);
+  if (pass == 0) k_pclndt_derivatives<true><<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, nl, src, n, per, P, d_partials);
+  else if (pass == 1) k_pclndt_derivatives<false><<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, nl, src, n, per, P, d_partials);
+  else if (pass == 2) k_pclndt_hessian<<<nb, 256, 0, stream>>>(view_of2(map), leaves, leaves_f, nl, src, n, per, P, d_partials);
   else k_pclndt_score<<<nb, 256, 0, stream>>>(view_of2(map), leaves, src, n, per, P, gauss_d3, d_partials);
   k_pclndt_reduce<<<1, 1024, 0, stream>>>(d_partials, nb, d_out);
 }

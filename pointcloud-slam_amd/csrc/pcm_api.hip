@@ -244,6 +244,13 @@ bool uses_neighbour_lists(const pcm_ctx* c) {
   return (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) != 0 || c->map_uses >= 2;
 }
 
+// pclomp NDT: the neighbour-leaf lists of the context's grid, or an empty view (the cells are then looked up one by one)
+TargetView ndt_lists_view(const pcm_ctx* c) {
+  const bool on = c->cfg.model == PCM_MODEL_NDT_OMP && c->nlists.valid && c->nlists.for_ndt && c->nlists.num_neighbors == c->cfg.num_neighbors &&
+                  !(c->cfg.flags & PCM_FLAG_NO_NEIGHBOUR_LISTS);
+  return on ? view_of_lists(c->nlists) : TargetView{};
+}
+
 // lazy (re)build of everything the residual kernel needs
 int prepare(pcm_ctx* c) {
   if (c->src.n == 0 || c->tgt.n == 0) { c->err = "align before setInputSource/setInputTarget"; return PCM_ERR_NO_INPUT; }
@@ -296,6 +303,20 @@ int prepare(pcm_ctx* c) {
       int rc = build_pclndt_leaves(c->stream, c->map, c->pleaf, c->pleaf_f, &c->err);
       if (rc != PCM_OK) return rc;
       c->pleaf_valid = true;
+      c->nlists.valid = false;
+    }
+    // neighbour-leaf lists of the grid (neighbour_lists.hip): same policy as the point-to-plane candidate lists -- from the second
+    // registration against the target on, or with the grid when PCM_FLAG_NEIGHBOUR_LISTS asks for it
+    const bool want_lists = !c->nlists_failed && !(c->cfg.flags & PCM_FLAG_NO_NEIGHBOUR_LISTS) && ((c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) || c->map_uses >= 2);
+    if (want_lists && (!c->nlists.valid || !c->nlists.for_ndt || c->nlists.num_neighbors != c->cfg.num_neighbors)) {
+      int rc = build_neighbour_lists(c->stream, c->map, c->cfg.num_neighbors, &c->nlists, &c->err, c->pleaf);
+      if (rc != PCM_OK) {
+        if (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) return rc;
+        c->nlists_failed = true;
+        c->nlists.release();
+        c->err.clear();
+        (void)hipGetLastError();
+      }
     }
     uint32_t per = 0;
     const size_t need = (size_t)pclndt_workgroups((uint32_t)c->src.n, &per) * 48;
@@ -822,7 +843,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
 
 // one pclomp NDT pass on the device: launch, read the 48-double row back (pass 0/1: H, g, score; pass 2: H)
 int pclndt_eval(pcm_ctx* c, int pass, const NdtOmpParams& P, ndtomp::Eval* e, double gauss_d3 = 0.0) {
-  launch_pclndt_pass(c->stream, c->map, c->pleaf, c->pleaf_f, c->src.d_pts, (uint32_t)c->src.n, P, pass, c->ndt_partials, c->ndt_out, gauss_d3);
+  launch_pclndt_pass(c->stream, c->map, c->pleaf, c->pleaf_f, ndt_lists_view(c), c->src.d_pts, (uint32_t)c->src.n, P, pass, c->ndt_partials, c->ndt_out, gauss_d3);
   HIPCK(c, hipGetLastError());
   HIPCK(c, hipMemcpyAsync(c->ndt_out_host, c->ndt_out, sizeof(double) * 48, hipMemcpyDeviceToHost, c->stream));
   HIPCK(c, hipStreamSynchronize(c->stream));
@@ -902,7 +923,7 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   int max_blocks = 1;
   for (int i = 0; i < n; i++) {
     pcm_ctx* c = ctxs[i];
-    w.h_objs[i] = make_ndt_object(c->map, c->pleaf, c->pleaf_f, c->src.d_pts, (uint32_t)c->src.n, c->ndt_partials);
+    w.h_objs[i] = make_ndt_object(c->map, c->pleaf, c->pleaf_f, ndt_lists_view(c), c->src.d_pts, (uint32_t)c->src.n, c->ndt_partials);
     max_blocks = std::max(max_blocks, (int)w.h_objs[i].nblocks);
     ndtomp::ndt_machine_start(w.h_ms[i], guesses + 16 * (size_t)i, (double)c->cfg.ndt_step_size, c->cfg.translation_eps, (double)c->cfg.ndt_outlier_ratio,
                               c->cfg.voxel_resolution, c->cfg.max_iterations, c->cfg.num_neighbors);
@@ -932,8 +953,9 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   // ragged end of its pass overlap the other's pass; more groups only add launches and host-side waiting.
   size_t total_points = 0;
   for (int i = 0; i < n; i++) total_points += ctxs[i]->src.n;
-  // (the 27-cell searches -- KDTREE, DIRECT26 -- lose with two groups: 1 570 -> 1 213 at 32 scans; their pass keeps the device busy alone)
-  const bool wide = c0->cfg.num_neighbors == 0 || c0->cfg.num_neighbors > 7;
+  // (the 27-cell searches -- KDTREE, DIRECT26 -- lose with two groups while they look their cells up one by one: 1 570 -> 1 213 at 32
+  // scans, their pass keeps the device busy alone; on the grid's neighbour-leaf lists they gain like the others: 2 760 -> 3 203)
+  const bool wide = (c0->cfg.num_neighbors == 0 || c0->cfg.num_neighbors > 7) && ndt_lists_view(c0).pts == nullptr;
   int ngroups = total_points <= 1000000 ? std::min(n, 4) : (wide ? 1 : std::min(n, 2));
   if (const char* e = getenv("PCM_NDT_GROUPS")) ngroups = std::max(1, std::min(n, atoi(e)));   // measurements only
   std::vector<Group> groups((size_t)ngroups);

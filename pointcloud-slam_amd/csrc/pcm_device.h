@@ -223,6 +223,7 @@ struct NdtObject {
   TargetView tg;
   const PclLeaf* leaves;
   const PclLeafF* leaves_f;
+  TargetView nl;          // neighbour-leaf lists of the grid (neighbour_lists.hip); pts == nullptr: none, the cells are looked up one by one
   const float4* src;
   uint32_t n, per;        // scan points, points per workgroup
   int32_t nblocks, pad;   // workgroup rows of a pass

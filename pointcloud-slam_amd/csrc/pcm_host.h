@@ -136,10 +136,11 @@ struct NeighbourLists {
   size_t start_cap = 0, pts_cap = 0, num_candidates = 0;
   uint32_t num_lists = 0;
   int num_neighbors = 0;      // the neighbourhood the lists were built for
+  bool for_ndt = false;       // entries are neighbour leaves of a pclomp NDT grid (centroid, leaf index) instead of map points
   bool valid = false;
   void release();
 };
-int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int num_neighbors, NeighbourLists* out, std::string* err);
+int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int num_neighbors, NeighbourLists* out, std::string* err, const PclLeaf* ndt_leaves = nullptr);
 TargetView view_of_lists(const NeighbourLists& l);
 void launch_linearize_lists(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);
 void launch_linearize_reforder(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);
@@ -164,10 +165,10 @@ int build_vgc_voxels(hipStream_t stream, const TargetMap& map, const double* d_c
 int build_pclndt_leaves(hipStream_t stream, const TargetMap& map, PclLeaf* d_out, PclLeafF* d_out_f, std::string* err);
 int pclndt_workgroups(uint32_t n, uint32_t* per_out);
 namespace ndtomp { struct NdtMachine; }
-NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, double* d_partials);
+NdtObject make_ndt_object(const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const TargetView& nl, const float4* src, uint32_t n, double* d_partials);
 // one round of a batched pclomp NDT registration: the pass every live object waits for, then the sums + solver step per object
 void launch_pclndt_batch_round(hipStream_t stream, const NdtObject* d_objs, ndtomp::NdtMachine* d_ms, int nobj, int max_blocks, unsigned char* d_flags_row);
-void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
+void launch_pclndt_pass(hipStream_t stream, const TargetMap& map, const PclLeaf* leaves, const PclLeafF* leaves_f, const TargetView& nl, const float4* src, uint32_t n, const NdtOmpParams& P, int pass, double* d_partials, double* d_out,
                         double gauss_d3 = 0.0);   // pass 3: calculateScore (needs gauss_d3)
 void launch_init_states(hipStream_t stream, PairState* d_states, const float* d_guesses, int npairs, int max_iterations, int window, unsigned int* d_queue);
 void launch_pack_results(hipStream_t stream, const PairState* d_states, pcm_result* d_results, int npairs);

@@ -88,3 +88,34 @@ def test_identity_guess_small_epsilon_and_batch(pcm, synth):
     batch = pcm.align_batch(regs, np.stack([q.guess for q in pairs]))
     for s, b in zip(singles, batch):
         assert np.array_equal(s.T64, b.T64)
+
+
+@pytest.mark.parametrize("nn", [0, 1, 7, 27])
+@pytest.mark.parametrize("res", [1.0, 0.5])
+def test_neighbour_leaf_lists_change_nothing(pcm, pair_dense, nn, res):
+    """PCM_FLAG_NEIGHBOUR_LISTS (16): the passes read the grid's neighbour-leaf lists (built with the leaves) instead of looking the
+    cells up one by one (64 = never): the same leaves in the same order, hence identical sums, poses and evaluation counts -- single
+    passes, single aligns, batched aligns; the default builds the lists at a target's second registration."""
+    p = pair_dense
+    kw = dict(voxel_resolution=res, num_neighbors=nn)
+    a = pcm.PclNdtRegistration(0, flags=16, **kw)
+    b = pcm.PclNdtRegistration(0, flags=64, **kw)
+    c = pcm.PclNdtRegistration(0, **kw)
+    for g in (a, b, c):
+        g.set_input_target(p.submap); g.set_input_source(p.scan)
+    for T in (p.guess, p.T_gt):
+        pv = _pvec(T)
+        for kind in ("float", None, "double"):
+            ra, rb = a.ndt_derivatives(pv, kind), b.ndt_derivatives(pv, kind)
+            assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+    ra, rb = a.align(p.guess), b.align(p.guess)
+    rc = [c.align(p.guess) for _ in range(3)][-1]     # the third registration against the target runs on lists built at the second
+    for r in (ra, rc):
+        assert np.array_equal(r.T64, rb.T64) and r.iterations == rb.iterations and r.num_linearize == rb.num_linearize
+    p2 = [pcm.PclNdtRegistration(0, flags=f, **kw) for f in (16, 16, 64, 64)]
+    for g in p2:
+        g.set_input_target(p.submap); g.set_input_source(p.scan)
+    guesses = np.stack([p.guess, p.guess])
+    ba, bb = pcm.align_batch(p2[:2], guesses), pcm.align_batch(p2[2:], guesses)
+    for x, y in zip(ba, bb):
+        assert np.array_equal(x.T64, y.T64) and x.iterations == y.iterations
