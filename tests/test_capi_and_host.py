@@ -47,6 +47,22 @@ def test_struct_layouts_match_header(pcm):
     assert got == want
 
 
+def test_flag_constants_match_header(pcm):
+    """Every PCM_FLAG_* / PCM_ERR_* / PCM_COV_* constant of the Python binding has the value include/pcm_amd.h defines."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pcm_amd.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(PCM_(?:FLAG|ERR|COV)_[A-Z0-9_]+)\s+(-?\d+)", hdr)}
+    assert {"PCM_FLAG_NEIGHBOUR_LISTS", "PCM_FLAG_NO_NEIGHBOUR_LISTS", "PCM_FLAG_REFERENCE_KNN_ORDER", "PCM_FLAG_LIO_REFERENCE_SEMANTICS"} <= set(defs)
+    seen = 0
+    for name, value in defs.items():
+        if hasattr(pcm.capi, name):
+            assert getattr(pcm.capi, name) == value, name
+            seen += 1
+    assert seen >= 7
+    flags = [v for k, v in defs.items() if k.startswith("PCM_FLAG_")]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)   # distinct single bits
+
+
 def test_default_config_is_the_reference_defaults(pcm):
     from pointcloud_slam_amd import capi
     L = pcm.load_library()
