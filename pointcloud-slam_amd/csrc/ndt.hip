@@ -156,10 +156,23 @@ __global__ void __launch_bounds__(256, 3) k_ndt(const PairDesc* __restrict__ des
     }
     int cbx = 0x7fffffff, cby = 0, cbz = 0;
     uint32_t slot = ~0u, vox_base = 0;
+    // a target that is registered against again keeps, for every voxel a query can fall into, the row of its nO neighbour voxels
+    // (neighbour_lists.hip): one probe of that index instead of nO cell look-ups one after the other
+    const bool rows = !TRIAL && d.nl.pts != nullptr && kp.nb_range == 0;
+    const int32_t* row = nullptr;
+    if (rows && inrange) {
+      int rbx = 0x7fffffff, rby = 0, rbz = 0;
+      uint32_t rslot = ~0u, rbase = 0;
+      const int lr = voxel_lookup(d.nl, cx, cy, cz, rbx, rby, rbz, rslot, rbase);
+      if (lr >= 0) row = reinterpret_cast<const int32_t*>(d.nl.pts) + (size_t)lr * nO;
+    }
     for (int k = 0; k < nO; k++) {
       int v;
       if (TRIAL) {
         v = *(const PCM_GLOBAL int32_t*)(d.corr + (size_t)i * nO + k);
+      } else if (rows) {
+        v = row ? *(const PCM_GLOBAL int32_t*)(row + k) : -1;
+        *(PCM_GLOBAL int32_t*)(d.corr + (size_t)i * nO + k) = v;
       } else {
         int ox, oy, oz;
         bool listed = true;

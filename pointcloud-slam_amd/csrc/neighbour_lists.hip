@@ -158,6 +158,22 @@ __global__ void k_nl_leaf_lists(const float4* __restrict__ centres, uint32_t nd,
   if (!FILL) len[r] = n;
 }
 
+// fast_gicp NDTCuda / VGICP of the CUDA core (ndt.hip k_ndt): the voxel of every neighbour offset of a list voxel, in the offset order
+// of ndt_cuda.cu:35-88 (DIRECT1 / 7 / 27), -1 where the cell is empty -- a fixed row of nO indices per list voxel, so the pass reads
+// one row behind one probe instead of probing nO cells one after the other.
+__global__ void k_nl_voxel_slots(const float4* __restrict__ centres, uint32_t nd, TargetView tg, int mode, int nO, int32_t* __restrict__ out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nd) return;
+  const float4 c = centres[r];
+  const int cx = voxel_coord(c.x, tg.res, tg.inv_res, mode), cy = voxel_coord(c.y, tg.res, tg.inv_res, mode), cz = voxel_coord(c.z, tg.res, tg.inv_res, mode);
+  BrickCursor cur;
+  for (int k = 0; k < nO; k++) {
+    int ox, oy, oz;
+    nl_ndt_offset(nO, k, ox, oy, oz);   // 7: {0, +x, -x, +y, -y, +z, -z}; 27: i, j, k loops -- the order of both references
+    out[(size_t)r * nO + k] = nl_voxel_rank(tg, cur, cx + ox, cy + oy, cz + oz);
+  }
+}
+
 TargetView view_of_map(const TargetMap& m) {
   TargetView v{};
   v.pts = m.pts; v.vox_start = m.vox_start; v.bricks = m.bricks; v.bmask = m.bmask; v.bpref = m.bpref; v.gvox = m.gvox;
@@ -171,7 +187,7 @@ void NeighbourLists::release() {
   index.release();
   if (start) hipFree(start);
   if (pts) hipFree(pts);
-  start = nullptr; pts = nullptr; start_cap = 0; pts_cap = 0; num_lists = 0; num_candidates = 0; num_neighbors = 0; valid = false; for_ndt = false;
+  start = nullptr; pts = nullptr; start_cap = 0; pts_cap = 0; num_lists = 0; num_candidates = 0; num_neighbors = 0; valid = false; kind = 0;
 }
 
 TargetView view_of_lists(const NeighbourLists& l) {
@@ -185,11 +201,11 @@ TargetView view_of_lists(const NeighbourLists& l) {
 // Build the candidate lists of `map` for the neighbourhood `nn` (7 / 19 / 27 cells); with `ndt_leaves` (pclomp NDT: nn = 0 for the
 // KDTREE search, 1 / 7 / 27) the lists hold neighbour LEAVES instead of points.  Host syncs: the number of dilated voxels, the index
 // build's own, the total list length.
-int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, NeighbourLists* out, std::string* err, const PclLeaf* ndt_leaves) {
+int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, NeighbourLists* out, std::string* err, const PclLeaf* ndt_leaves, bool voxel_slots) {
   out->valid = false;
   const int mode = map.coord_mode;
-  if (!map.valid || (mode != COORD_ROUND && mode != COORD_FLOOR_MUL)) { *err = "neighbour lists need a point-to-plane or pclomp NDT map"; return PCM_ERR_UNSUPPORTED; }
-  if (ndt_leaves ? (nn != 0 && nn != 1 && nn != 7 && nn != 27) : (nn != 1 && nn != 7 && nn != 19 && nn != 27)) { *err = "neighbour lists: unsupported neighbourhood"; return PCM_ERR_INVALID_ARGUMENT; }
+  if (!map.valid || (mode != COORD_ROUND && mode != COORD_FLOOR_MUL && mode != COORD_FLOOR_HALF)) { *err = "neighbour lists: unsupported voxel convention"; return PCM_ERR_UNSUPPORTED; }
+  if (voxel_slots ? (nn != 1 && nn != 7 && nn != 27) : ndt_leaves ? (nn != 0 && nn != 1 && nn != 7 && nn != 27) : (nn != 1 && nn != 7 && nn != 19 && nn != 27)) { *err = "neighbour lists: unsupported neighbourhood"; return PCM_ERR_INVALID_ARGUMENT; }
   const int nset = nn == 0 ? 27 : nn;   // cells of the neighbourhood (the SET is the same in the iVox and the pcl order: c_nearby's prefixes)
   const uint32_t nvox = map.num_voxels;
   const size_t nk = (size_t)nvox * nset;
@@ -197,7 +213,7 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
   {   // room for them?  27 x 16 B per map point for the lists, ~56 B per (voxel, offset) key while they are built; a quarter of the
       // free memory stays untouched (the caller's next targets, the scratch of the passes)
     size_t free_b = 0, total_b = 0;
-    const size_t need = (ndt_leaves ? (size_t)nvox : (size_t)map.num_points) * nset * sizeof(float4) + nk * 56 + ((size_t)64 << 20);
+    const size_t need = ((ndt_leaves || voxel_slots) ? (size_t)nvox : (size_t)map.num_points) * nset * sizeof(float4) + nk * 56 + ((size_t)64 << 20);
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b - free_b / 4) {
       *err = "neighbour lists: " + std::to_string(need >> 20) + " MiB needed, " + std::to_string(free_b >> 20) + " MiB of device memory free";
       return PCM_ERR_HIP;
@@ -233,7 +249,7 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
     CK(hipMallocAsync(&tmp2, tmp2_bytes, stream));
     CK(rocprim::exclusive_scan(tmp2, tmp2_bytes, flag, pos, 0u, nk, rocprim::plus<uint32_t>(), stream));
     CK(hipMallocAsync(reinterpret_cast<void**>(&centres), sizeof(float4) * nk, stream));   // at most one per key
-    k_nl_centres<<<nb, 256, 0, stream>>>(keys_s, flag, pos, (uint32_t)nk, map.res, mode == COORD_ROUND ? 0.f : 0.5f, centres, d_cnt);
+    k_nl_centres<<<nb, 256, 0, stream>>>(keys_s, flag, pos, (uint32_t)nk, map.res, mode == COORD_ROUND ? 0.f : mode == COORD_FLOOR_MUL ? 0.5f : 1.0f, centres, d_cnt);
     CK(hipGetLastError());
     CK(hipMemcpyAsync(&h_cnt[0], d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     CK(hipStreamSynchronize(stream));
@@ -243,6 +259,24 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
     rc = build_target_map(stream, centres, &nd, map.res, mode, false, 0u, &out->index, err);
     if (rc != PCM_OK) goto done;
     if (out->index.num_voxels != nd || out->index.num_points != nd) { *err = "neighbour lists: index does not hold one voxel per list"; rc = PCM_ERR_INTERNAL; goto done; }
+    if (voxel_slots) {   // a fixed row of nn voxel indices per list voxel, kept in the `pts` allocation
+      const size_t words = (size_t)nd * nn, cells = (words + 3) / 4 + 4;
+      if (out->pts_cap < cells) {
+        if (out->pts) hipFree(out->pts);
+        out->pts = nullptr; out->pts_cap = 0;
+        CK(hipMalloc(reinterpret_cast<void**>(&out->pts), sizeof(float4) * cells));
+        out->pts_cap = cells;
+      }
+      k_nl_voxel_slots<<<(nd + 127) / 128, 128, 0, stream>>>(out->index.pts, nd, view_of_map(map), mode, nn, reinterpret_cast<int32_t*>(out->pts));
+      CK(hipGetLastError());
+      CK(hipStreamSynchronize(stream));
+      out->num_lists = nd;
+      out->num_candidates = words;
+      out->num_neighbors = nn;
+      out->kind = 2;
+      out->valid = true;
+      goto done;
+    }
     // list lengths -> starts -> candidates
     if (out->start_cap < (size_t)nd + 1) {
       if (out->start) hipFree(out->start);
@@ -275,7 +309,7 @@ int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int nn, Neig
     out->num_lists = nd;
     out->num_candidates = total;
     out->num_neighbors = nn;
-    out->for_ndt = ndt_leaves != nullptr;
+    out->kind = ndt_leaves ? 1 : 0;
     out->valid = true;
   }
 done:

@@ -244,9 +244,17 @@ bool uses_neighbour_lists(const pcm_ctx* c) {
   return (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) != 0 || c->map_uses >= 2;
 }
 
+// fast_gicp NDTCuda (P2D / D2D) and VGICP of the CUDA core with a DIRECT neighbourhood: k_ndt reads rows of neighbour voxel indices
+bool uses_voxel_slot_lists(const pcm_ctx* c) {
+  const int m = c->cfg.model;
+  if (!(m == PCM_MODEL_NDT_P2D || m == PCM_MODEL_NDT_D2D || m == PCM_MODEL_VGICP_CUDA) || c->cfg.neighbor_search_radius > 0.f) return false;
+  if (c->nlists_failed || (c->cfg.flags & PCM_FLAG_NO_NEIGHBOUR_LISTS) || c->map.coord_mode != COORD_FLOOR_HALF) return false;
+  return (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) != 0 || c->map_uses >= 2;
+}
+
 // pclomp NDT: the neighbour-leaf lists of the context's grid, or an empty view (the cells are then looked up one by one)
 TargetView ndt_lists_view(const pcm_ctx* c) {
-  const bool on = c->cfg.model == PCM_MODEL_NDT_OMP && c->nlists.valid && c->nlists.for_ndt && c->nlists.num_neighbors == c->cfg.num_neighbors &&
+  const bool on = c->cfg.model == PCM_MODEL_NDT_OMP && c->nlists.valid && c->nlists.kind == 1 && c->nlists.num_neighbors == c->cfg.num_neighbors &&
                   !(c->cfg.flags & PCM_FLAG_NO_NEIGHBOUR_LISTS);
   return on ? view_of_lists(c->nlists) : TargetView{};
 }
@@ -278,12 +286,23 @@ int prepare(pcm_ctx* c) {
     c->map_uses = 0;
   }
   if (c->map_uses < 1000000) c->map_uses++;
-  if (uses_neighbour_lists(c) && (!c->nlists.valid || c->nlists.num_neighbors != c->cfg.num_neighbors)) {
+  if (uses_neighbour_lists(c) && (!c->nlists.valid || c->nlists.kind != 0 || c->nlists.num_neighbors != c->cfg.num_neighbors)) {
     // the candidate list of every voxel a query can fall into, built once per (static) target
     int rc = build_neighbour_lists(c->stream, c->map, c->cfg.num_neighbors, &c->nlists, &c->err);
     if (rc != PCM_OK) {
       if (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) return rc;   // asked for explicitly
       c->nlists_failed = true;                                   // e.g. no memory for them: the tile kernel serves this target
+      c->nlists.release();
+      c->err.clear();
+      (void)hipGetLastError();
+    }
+  }
+  if (uses_voxel_slot_lists(c) && (!c->nlists.valid || c->nlists.kind != 2 || c->nlists.num_neighbors != c->cfg.num_neighbors)) {
+    // fast_gicp NDTCuda / VGICP_CUDA with DIRECT1 / 7 / 27: rows of neighbour voxel indices, same policy as the candidate lists
+    int rc = build_neighbour_lists(c->stream, c->map, c->cfg.num_neighbors, &c->nlists, &c->err, nullptr, true);
+    if (rc != PCM_OK) {
+      if (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) return rc;
+      c->nlists_failed = true;
       c->nlists.release();
       c->err.clear();
       (void)hipGetLastError();
@@ -308,7 +327,7 @@ int prepare(pcm_ctx* c) {
     // neighbour-leaf lists of the grid (neighbour_lists.hip): same policy as the point-to-plane candidate lists -- from the second
     // registration against the target on, or with the grid when PCM_FLAG_NEIGHBOUR_LISTS asks for it
     const bool want_lists = !c->nlists_failed && !(c->cfg.flags & PCM_FLAG_NO_NEIGHBOUR_LISTS) && ((c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) || c->map_uses >= 2);
-    if (want_lists && (!c->nlists.valid || !c->nlists.for_ndt || c->nlists.num_neighbors != c->cfg.num_neighbors)) {
+    if (want_lists && (!c->nlists.valid || c->nlists.kind != 1 || c->nlists.num_neighbors != c->cfg.num_neighbors)) {
       int rc = build_neighbour_lists(c->stream, c->map, c->cfg.num_neighbors, &c->nlists, &c->err, c->pleaf);
       if (rc != PCM_OK) {
         if (c->cfg.flags & PCM_FLAG_NEIGHBOUR_LISTS) return rc;
@@ -495,7 +514,10 @@ void fill_desc(const pcm_ctx* c, PairDesc* d, double* partials) {
   d->tgt.inv_res = c->map.inv_res;
   d->tgt.res = c->map.res;
   d->tgt.gvox = c->map.gvox;
-  d->nl = (uses_neighbour_lists(c) && c->nlists.valid) ? view_of_lists(c->nlists) : TargetView{};
+  d->nl = TargetView{};
+  if (c->nlists.valid && c->nlists.num_neighbors == c->cfg.num_neighbors &&
+      ((uses_neighbour_lists(c) && c->nlists.kind == 0) || (uses_voxel_slot_lists(c) && c->nlists.kind == 2)))
+    d->nl = view_of_lists(c->nlists);
   d->src.pts = (c->cfg.sort_source && c->src_sorted) ? c->src_order : c->src.d_pts;
   if (is_gicp(c->cfg.model)) d->src.pts = c->srcmap.pts;   // brick-major copy of the scan: its covariances are in that order
   d->src_cov = c->src_cov;
@@ -669,7 +691,7 @@ int align_batch_impl(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_resu
   const bool counted_search = (g.flags & PCM_FLAG_COUNTED_SEARCH) != 0;   // k_linearize_counted (A/B)
   const bool ref_order = g.model == PCM_MODEL_P2PLANE && (g.flags & PCM_FLAG_REFERENCE_KNN_ORDER) != 0;   // neighbours in libstdc++'s nth_element order
   bool lists = g.model == PCM_MODEL_P2PLANE && !ref_order;   // k_linearize_lists: every context of the batch holds its map's candidate lists
-  for (int i = 0; i < n && lists; i++) lists = uses_neighbour_lists(ctxs[i]) && ctxs[i]->nlists.valid;
+  for (int i = 0; i < n && lists; i++) lists = uses_neighbour_lists(ctxs[i]) && ctxs[i]->nlists.valid && ctxs[i]->nlists.kind == 0;
   if (ref_order) {
     for (int i = 0; i < n; i++) {
       if (ctxs[i]->map.max_voxel_points > (uint32_t)kRefMaxVoxelPoints) {
@@ -830,7 +852,7 @@ int single_pass(pcm_ctx* c, const double T[16], bool linearize, double sums[kPar
     if (c->map.max_voxel_points > (uint32_t)kRefMaxVoxelPoints) { c->err = "PCM_FLAG_REFERENCE_KNN_ORDER supports at most " + std::to_string(kRefMaxVoxelPoints) + " points per voxel"; return PCM_ERR_UNSUPPORTED; }
     launch_linearize_reforder(c->stream, w->d_descs, w->d_states, kp1, 1, true);
   }
-  else if (linearize && uses_neighbour_lists(c) && c->nlists.valid) launch_linearize_lists(c->stream, w->d_descs, w->d_states, kp1, 1, true);
+  else if (linearize && uses_neighbour_lists(c) && c->nlists.valid && c->nlists.kind == 0) launch_linearize_lists(c->stream, w->d_descs, w->d_states, kp1, 1, true);
   else if (linearize && (c->cfg.flags & PCM_FLAG_COUNTED_SEARCH)) launch_linearize_counted(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr);
   else if (linearize) launch_linearize(c->stream, w->d_descs, w->d_states, kp1, 1, true, nullptr, false);
   else launch_trial(c->stream, w->d_descs, w->d_states, kp1, 1);

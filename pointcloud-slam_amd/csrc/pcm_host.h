@@ -136,11 +136,11 @@ struct NeighbourLists {
   size_t start_cap = 0, pts_cap = 0, num_candidates = 0;
   uint32_t num_lists = 0;
   int num_neighbors = 0;      // the neighbourhood the lists were built for
-  bool for_ndt = false;       // entries are neighbour leaves of a pclomp NDT grid (centroid, leaf index) instead of map points
+  int kind = 0;               // 0: candidate points (P2PLANE); 1: neighbour leaves of a pclomp NDT grid (centroid, leaf index); 2: rows of neighbour voxel indices (k_ndt)
   bool valid = false;
   void release();
 };
-int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int num_neighbors, NeighbourLists* out, std::string* err, const PclLeaf* ndt_leaves = nullptr);
+int build_neighbour_lists(hipStream_t stream, const TargetMap& map, int num_neighbors, NeighbourLists* out, std::string* err, const PclLeaf* ndt_leaves = nullptr, bool voxel_slots = false);
 TargetView view_of_lists(const NeighbourLists& l);
 void launch_linearize_lists(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);
 void launch_linearize_reforder(hipStream_t stream, const PairDesc* d_descs, const PairState* d_states, const KernelParams& kp, int npairs, bool write_planes);

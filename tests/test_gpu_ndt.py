@@ -99,3 +99,28 @@ def test_ndt_batch_and_swap(pcm, synth):
     g = pcm.NdtRegistration(0); g.set_input_target(p.scan); g.set_input_source(p.submap)
     g.swap_source_and_target()
     assert np.array_equal(g.align(p.guess).T64, singles[0].T64)
+
+
+@pytest.mark.parametrize("model", ["NDT_P2D", "NDT_D2D", "VGICP_CUDA"])
+@pytest.mark.parametrize("nn", [1, 7, 27])
+def test_neighbour_voxel_rows_change_nothing(pcm, pair_dense, model, nn):
+    """PCM_FLAG_NEIGHBOUR_LISTS (16): k_ndt reads, for the voxel a point falls into, the row of its neighbour voxels built with the
+    target (64 = never: every cell is looked up): the same correspondences, hence identical sums, trial costs and poses; the
+    default builds the rows at a target's second registration."""
+    p = pair_dense
+    cls = pcm.VgicpCudaRegistration if model == "VGICP_CUDA" else pcm.NdtRegistration
+    kw = dict(voxel_resolution=1.0, num_neighbors=nn)
+    if model != "VGICP_CUDA":
+        kw["model"] = model
+    regs = {f: cls(0, flags=f, **kw) for f in (16, 64, 0)}
+    for g in regs.values():
+        g.set_input_target(p.submap); g.set_input_source(p.scan)
+    for T in (p.guess.astype(np.float64), p.T_gt):
+        ra, rb = regs[16].evaluate_cost(T), regs[64].evaluate_cost(T)
+        assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2]) and ra[3] == rb[3]
+        T2 = T.copy(); T2[:3, 3] += [0.02, -0.01, 0.01]
+        assert regs[16].compute_error(T2) == regs[64].compute_error(T2)
+    ra, rb = regs[16].align(p.guess), regs[64].align(p.guess)
+    rc = [regs[0].align(p.guess) for _ in range(3)][-1]
+    for r in (ra, rc):
+        assert np.array_equal(r.T64, rb.T64) and r.iterations == rb.iterations and r.num_inliers == rb.num_inliers

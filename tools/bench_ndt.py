@@ -12,6 +12,7 @@ ap.add_argument("--cpu", type=int, default=1)
 ap.add_argument("--lib", default="", help="A/B: load this build of the library")
 ap.add_argument("--eps", type=float, default=0.01, help="pclomp NDT transformation epsilon: 0.01 at the call sites (jueying_slam/src/localization.cpp:170-175), 0.1 the class default")
 ap.add_argument("--models", default="NDT_OMP,NDT_OMP_KDTREE,NDT_D2D,NDT_P2D")
+ap.add_argument("--flags", type=int, default=0, help="pcm_config.flags (64 = PCM_FLAG_NO_NEIGHBOUR_LISTS: every cell looked up, the A/B partner)")
 a = ap.parse_args()
 synth = importlib.import_module("pointcloud-slam_amd.synth")
 scene = synth.scene_for_points(1234, a.map, 60.0)          # >6 points per 0.5 m voxel on surfaces
@@ -33,7 +34,7 @@ for mname in a.models.split(","):
     regs = []
     t0 = time.perf_counter()
     for sc in scans:
-        r = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=nn, translation_eps=a.eps) if model == "NDT_OMP" else pcm.NdtRegistration(0, model=model, voxel_resolution=0.5, num_neighbors=7)
+        r = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=nn, translation_eps=a.eps, flags=a.flags) if model == "NDT_OMP" else pcm.NdtRegistration(0, model=model, voxel_resolution=0.5, num_neighbors=7, flags=a.flags)
         r.set_input_target(d_map); regs.append(r)
     d_scans = [torch.from_numpy(s).cuda() for s in scans]
     for r, s in zip(regs, d_scans):
