@@ -38,6 +38,16 @@ def test_config2_pair_100k_vs_1m_matches_oracle(pcm, synth, optimizer):
     assert n1 == n0 and rel_err(H1, H0) < HB_RTOL and rel_err(b1, b0) < HB_RTOL and abs(c1 - c0) <= HB_RTOL * c0
     dgt = pose_error(rg.T64, p.T_gt)
     assert dgt[0] < 0.05 and dgt[1] < 2e-3                           # and it is the right pose, not just the same one
+    # the registrations that follow run on the candidate lists built with the 1 M-point map (the kernel the bench line is timed on):
+    # the same result bit for bit, as the tile kernel (flags 64) gives it on an object of its own
+    t = pcm.P2PlaneRegistration(0, optimizer=optimizer, flags=64)
+    t.set_input_target(p.submap); t.set_input_source(p.scan)
+    rt = t.align(p.guess)
+    for _ in range(2):
+        r2 = g.align(p.guess)
+        assert np.array_equal(r2.T64, rt.T64) and np.array_equal(r2.T64, rg.T64) and r2.iterations == rt.iterations and r2.num_inliers == rt.num_inliers and r2.cost == rt.cost
+    st = g.stats()
+    assert st["target_voxels"] > 100000
 
 
 def test_config4_ndt_100k_scan_on_10m_point_grid_matches_oracle(pcm, synth):
@@ -59,6 +69,16 @@ def test_config4_ndt_100k_scan_on_10m_point_grid_matches_oracle(pcm, synth):
     assert abs(g.ndt_score(rg.T) - o.ndt_score(rg.T)) <= 1e-12 * abs(o.ndt_score(rg.T))   # calculateScore at the result
     e0, e1 = pose_error(p.guess, p.T_gt), pose_error(rg.T64, p.T_gt)
     assert e1[0] < 0.5 * e0[0]                                           # epsilon 0.01 stops early, but it did register
+    # the registrations that follow run on the grid's neighbour-leaf lists (built at the second one): the same leaves in the same order,
+    # the same result bit for bit -- for the DIRECT7 search and for KDTREE, the search of the call sites' default
+    for _ in range(2):
+        r2 = g.align(p.guess)
+        assert np.array_equal(r2.T64, rg.T64) and r2.iterations == rg.iterations and r2.num_linearize == rg.num_linearize
+    g.set_num_neighbors(0)                      # the lists are rebuilt for the other search at once (the grid has been used before)
+    t = pcm.PclNdtRegistration(0, voxel_resolution=0.5, num_neighbors=0, translation_eps=0.01, flags=64)   # never on lists
+    t.set_input_target(p.submap); t.set_input_source(p.scan)
+    rk, rt = g.align(p.guess), t.align(p.guess)
+    assert rt.converged and np.array_equal(rk.T64, rt.T64) and rk.iterations == rt.iterations and rk.num_linearize == rt.num_linearize
 
 
 def sliding_map_scenario(synth, n_frames=20, scan_points=20000, capacity=1_000_000, res=0.5):
