@@ -902,11 +902,13 @@ struct NdtBatchWs {
   unsigned char* d_flags = nullptr;
   int cap = 0;
   size_t cap_flags = 0;
+  hipStream_t gst[4] = {nullptr, nullptr, nullptr, nullptr};   // streams of the lock-step groups, created back to back
 };
 
 void free_ndt_batch_ws(void* p) {
   NdtBatchWs* w = static_cast<NdtBatchWs*>(p);
   if (!w) return;
+  for (hipStream_t st : w->gst) if (st) (void)hipStreamDestroy(st);
   if (w->d_objs) hipFree(w->d_objs);
   if (w->d_ms) hipFree(w->d_ms);
   if (w->h_objs) hipHostFree(w->h_objs);
@@ -979,12 +981,20 @@ int pclndt_align_batch(pcm_ctx* const* ctxs, int n, const float* guesses, pcm_re
   // scans, their pass keeps the device busy alone; on the grid's neighbour-leaf lists they gain like the others: 2 760 -> 3 203)
   const bool wide = (c0->cfg.num_neighbors == 0 || c0->cfg.num_neighbors > 7) && ndt_lists_view(c0).pts == nullptr;
   int ngroups = total_points <= 1000000 ? std::min(n, 4) : (wide ? 1 : std::min(n, 2));
-  if (const char* e = getenv("PCM_NDT_GROUPS")) ngroups = std::max(1, std::min(n, atoi(e)));   // measurements only
+  if (const char* e = getenv("PCM_NDT_GROUPS")) ngroups = std::max(1, std::min(std::min(n, 4), atoi(e)));   // measurements only
   std::vector<Group> groups((size_t)ngroups);
   for (int g = 0; g < ngroups; g++) {
     Group& G = groups[(size_t)g];
     G.lo = (int)((long long)n * g / ngroups); G.hi = (int)((long long)n * (g + 1) / ngroups);
-    G.launched = 0; G.confirmed = 0; G.done = false; G.st = ctxs[G.lo]->stream; G.max_blocks = 1;
+    G.launched = 0; G.confirmed = 0; G.done = false; G.max_blocks = 1;
+    // Streams of the groups' own, created back to back: HIP deals streams onto a handful of hardware queues in creation order, and two
+    // groups whose streams share a queue do not overlap.  (With the streams of the groups' first objects the first batch of a process
+    // ran at 3 225 registrations/s and a second batch of objects created later in the same process at 2 016, or the other way round.)
+    if (ngroups == 1) G.st = ctxs[G.lo]->stream;
+    else {
+      if (!w.gst[g]) HIPCK(c0, hipStreamCreateWithFlags(&w.gst[g], hipStreamNonBlocking));
+      G.st = w.gst[g];
+    }
     for (int i = G.lo; i < G.hi; i++) G.max_blocks = std::max(G.max_blocks, (int)w.h_objs[i].nblocks);
   }
   const auto t_start = std::chrono::steady_clock::now();
