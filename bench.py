@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--stagger", type=float, default=0.5, help="start offset between the pipeline slots, in units of one warm pass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured path); gloo only to rehearse the N>1 control flow with several ranks sharing one GPU")
+    ap.add_argument("--slot-streams", type=int, default=1, help="1: every pipeline slot runs on a stream of its own, created back to back; 0: on the stream of its first object")
     ap.add_argument("--collectives-at-one", type=int, default=0,
                     help="1: at N=1 still create the process group and run the per-pass all-gather (world size 1): executes the RCCL path of N>1 on one GPU")
     args = ap.parse_args()
@@ -247,6 +248,14 @@ def main():
         lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
         for j in range(S):
             st_j = torch.cuda.Stream(device=dev, priority=(hi_p if j == 0 else lo_p))
+            slot_streams.append(st_j)
+            for r in (reg_sets[j] if rotate else [regs[i] for i in groups[j]]):
+                r.set_stream(st_j.cuda_stream)
+    elif S > 1 and args.slot_streams:
+        # streams of the slots' own, created back to back: HIP deals streams onto a handful of hardware queues in creation order, and two
+        # slots whose streams share a queue do not overlap (measured on the pclomp NDT groups: 3 200 against 2 000 registrations/s)
+        for j in range(S):
+            st_j = torch.cuda.Stream(device=dev)
             slot_streams.append(st_j)
             for r in (reg_sets[j] if rotate else [regs[i] for i in groups[j]]):
                 r.set_stream(st_j.cuda_stream)
